@@ -1,0 +1,11 @@
+"""MI355X-native gradient-weighted feature back-projection (the hot path of backproject.py of
+JojiJoseph/3dgs-gradient-backprojection), hand-written HIP kernels behind a C ABI (include/gwbp.h).
+
+    from gsbp_amd import rasterization            # drop-in for `from gsplat import rasterization`
+    from gsbp_amd import create_feature_field     # fused counterpart of create_feature_field_lseg/_dino
+"""
+from . import synthetic  # noqa: F401
+from ._lib import GwbpError, build, lib  # noqa: F401
+from .backproject import create_feature_field, finalize_reference, prune_mask, reduce_partials  # noqa: F401
+from .engine import Engine  # noqa: F401
+from .rasterization import rasterization, spherical_harmonics  # noqa: F401

@@ -1,0 +1,105 @@
+"""ctypes binding of libgwbp.so (the C ABI in include/gwbp.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, every operator raises.
+`import torch` must happen before the library is loaded so that libgwbp.so binds to the libamdhip64.so.7
+that PyTorch-ROCm already mapped (one HIP runtime per process).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgwbp.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+EXPORTS = [
+    "gwbp_version", "gwbp_last_error_string", "gwbp_workspace_size", "gwbp_project", "gwbp_bin_sort",
+    "gwbp_blend_weights", "gwbp_scatter", "gwbp_render", "gwbp_backproject_view", "gwbp_finalize",
+    "gwbp_accumulate_stats", "gwbp_read_stats", "gwbp_dump_pairs",
+]
+
+
+class View(C.Structure):
+    _fields_ = [("viewmat", C.c_float * 16), ("K", C.c_float * 9), ("width", C.c_int32), ("height", C.c_int32),
+                ("near_plane", C.c_float), ("far_plane", C.c_float), ("eps2d", C.c_float),
+                ("radius_clip", C.c_float)]
+
+
+class Caps(C.Structure):
+    _fields_ = [("n_gaussians", C.c_int64), ("isect_cap", C.c_int64), ("pair_cap", C.c_int64),
+                ("max_width", C.c_int32), ("max_height", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("n_isect", C.c_uint32), ("n_visible", C.c_uint32),
+                ("n_headers", C.c_uint32), ("pool_used", C.c_uint32), ("overflow", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+
+
+class GwbpError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into the in-tree libgwbp.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "gwbp.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s))
+    if stale:
+        if not os.path.exists("/opt/rocm/bin/hipcc"):
+            raise GwbpError("libgwbp.so is stale/missing and hipcc is not available to rebuild it")
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j8"])
+    return LIB_PATH
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GwbpError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU or PyTorch fallback for this path)")
+        L = C.CDLL(LIB_PATH)
+        L.gwbp_version.restype = C.c_char_p
+        L.gwbp_last_error_string.restype = C.c_char_p
+        for name in EXPORTS[2:]:
+            getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().gwbp_last_error_string().decode("utf-8", "replace")
+        kind = "invalid argument" if rc == -1 else "workspace too small" if rc == -2 else \
+            "unsupported" if rc == -3 else f"hipError {rc}"
+        raise GwbpError(f"{what} failed ({kind}): {msg}")
+
+
+def make_view(viewmat, K, width: int, height: int, near_plane=0.01, far_plane=1e10, eps2d=0.3,
+              radius_clip=0.0) -> View:
+    v = View()
+    vm = [float(x) for x in viewmat.detach().reshape(-1).cpu().tolist()]
+    kk = [float(x) for x in K.detach().reshape(-1).cpu().tolist()]
+    if len(vm) != 16 or len(kk) != 9:
+        raise ValueError("viewmat must be 4x4 and K 3x3")
+    v.viewmat[:] = vm
+    v.K[:] = kk
+    v.width, v.height = int(width), int(height)
+    v.near_plane, v.far_plane, v.eps2d, v.radius_clip = near_plane, far_plane, eps2d, radius_clip
+    return v
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,114 @@
+"""Feature-field builder: counterpart of create_feature_field_lseg / _dino (backproject.py:25-172, :175-298)
+and of the compressed variant (backproject_compressed.py:39-186) on top of the fused HIP path.
+
+Per view the reference does: rasterise(zeros [N,D]) -> (render*feats).sum().backward() -> grad.clone();
+rasterise(zeros [N,3]) -> render.sum().backward() -> grad[:,0]; F += ..; d += .. (backproject.py:115-151).
+Here one call (`Engine.backproject_view`) projects, sorts, blends ONCE and scatter-accumulates straight into
+F[N,D] and d[N].  Views shard across ranks (`synthetic.view_shard`); partial F/d are summed with ONE
+all-reduce (RCCL over xGMI when the process group backend is "nccl"), the 1e-12 of backproject.py:63 is
+added once after the reduction, then normalisation is row-local (backproject.py:166-169).
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Dict, Optional, Sequence
+
+import torch
+
+from .engine import Engine
+from .synthetic import view_shard
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def reduce_partials(F: torch.Tensor, d: torch.Tensor) -> None:
+    """The path's single exchange step: sum the per-rank partial accumulators."""
+    dist, _, world = _dist()
+    if world > 1:
+        dist.all_reduce(F, op=dist.ReduceOp.SUM)
+        dist.all_reduce(d, op=dist.ReduceOp.SUM)
+
+
+def finalize_reference(F: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+    """backproject.py:63,166-169 in plain torch (host logic used by the CPU/gloo tests; the GPU path calls
+    Engine.finalize -> gwbp_finalize)."""
+    den = 1e-12 + d
+    x = F / den[:, None]
+    x = x / x.norm(dim=-1, keepdim=True)
+    x[torch.isnan(x)] = 0
+    return x
+
+
+def create_feature_field(means, quats, scales, opacities, viewmats, K, width: int, height: int,
+                         feature_fn: Callable[[int], torch.Tensor], dim: int, reduction: str = "sum",
+                         encoder: Optional[torch.Tensor] = None, engine: Optional[Engine] = None,
+                         views: Optional[Sequence[int]] = None, view_fn=None, check_every: int = 0,
+                         return_partials: bool = False, verbose: bool = False):
+    """Build the [N, dim_out] per-Gaussian feature field.
+
+    means/quats/scales/opacities: post-activation Gaussians (backproject.py:55-57), device tensors.
+    viewmats [V,4,4], K [3,3]; feature_fn(v) -> feats[H,W,dim] float32 on the same device (stands in for the
+    LSeg/DINO forward of backproject.py:102-113 / :236-249).
+    reduction: "sum" (lseg, backproject.py:127,145) or "mean" (dino, backproject.py:263,283).
+    encoder [dim, dim_out]: backproject_compressed.py:127 (feats @ encoder before back-projection).
+    views: explicit list of view indices for this rank (default: interleaved shard over the process group).
+    view_fn: injection point for the per-view accumulate (tests drive the sharding/reduction logic on CPU).
+    """
+    dist, rank, world = _dist()
+    n = means.shape[0]
+    d_out = dim if encoder is None else encoder.shape[1]
+    dev = means.device
+    F = torch.zeros(n, d_out, device=dev, dtype=torch.float32)
+    d = torch.zeros(n, device=dev, dtype=torch.float32)
+    my_views = list(views) if views is not None else view_shard(viewmats.shape[0], rank, world)
+    if reduction == "sum":
+        sf, sd = 1.0, 1.0
+    elif reduction == "mean":
+        sf, sd = 1.0 / (height * width * d_out), 1.0 / (height * width * 3)
+    else:
+        raise ValueError(reduction)
+
+    if view_fn is None:
+        eng = engine or Engine(n, width, height, device=dev)
+        accum = torch.zeros(32, dtype=torch.uint8, device=dev)
+
+        def view_fn(v, feats):  # noqa: F811
+            view = eng.view(viewmats[v], K, width, height)
+            eng.backproject_view(view, means, quats, scales, opacities, feats, F, d, sf, sd)
+            eng.accumulate_stats(accum)
+    else:
+        eng, accum = None, None
+
+    t0 = time.time()
+    for i, v in enumerate(my_views):
+        feats = feature_fn(v)
+        if encoder is not None:
+            feats = feats @ encoder
+        view_fn(v, feats)
+        if eng is not None and check_every and (i + 1) % check_every == 0:
+            st = Engine.decode_stats(accum)
+            if st["overflow"]:
+                raise RuntimeError(f"workspace overflow (flags {st['overflow']}) at view {v}: enlarge isect_cap/pair_cap")
+    stats: Dict[str, int] = {}
+    if eng is not None:
+        stats = Engine.decode_stats(accum)  # synchronises
+        if stats["overflow"]:
+            raise RuntimeError(f"workspace overflow (flags {stats['overflow']}): enlarge isect_cap/pair_cap and rerun")
+    reduce_partials(F, d)
+    out = eng.finalize(F, d) if eng is not None else finalize_reference(F, d)
+    if verbose and rank == 0:
+        print("Time taken for feature backprojection", time.time() - t0)  # backproject.py:171
+    if return_partials:
+        return out, F, d, stats
+    return out
+
+
+def prune_mask(d: torch.Tensor) -> torch.Tensor:
+    """utils.prune_by_gradients (utils.py:222-271) keeps Gaussians whose accumulated colour-gradient norm is
+    > 0 over all views; that norm is 2/(3HW) * sum_v sum_p w, i.e. the mask is exactly d > 0."""
+    return d > 0

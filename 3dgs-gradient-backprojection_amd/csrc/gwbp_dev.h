@@ -1,0 +1,157 @@
+// gwbp_dev.h -- internal declarations shared by the HIP translation units of libgwbp.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gwbp.h"
+
+namespace gwbp {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---- constants of the arithmetic contract (gsplat 1.4.0 semantics) -------------
+constexpr float kAlphaMin = 0x1.010102p-8f;    // 1/255
+constexpr float kAlphaMax = 0x1.ff7ceep-1f;    // 0.999
+constexpr float kTMin = 0x1.a36e2ep-14f;       // 1e-4
+constexpr float kRadiusFloor = 0x1.47ae14p-7f; // 0.01
+constexpr float kClampMargin = 0x1.333334p-2f; // 0.3 (x/z clamp margin in tan_fov units)
+
+constexpr int kTile = GWBP_TILE;     // 16 x 16 pixels
+constexpr int kTilePix = 256;
+constexpr int kPage = 1024;          // weight-pool page (floats) grabbed per (tile, wave) stream
+constexpr int kSortItems = 4096;     // keys per sort block (256 threads x 16)
+constexpr int kScanBlock = 256;      // Gaussians per project/emit block
+
+// ---- device-resident tables -------------------------------------------------------------------------------
+// Projected Gaussian, 32 B, read by the blend kernel with two 16-B loads.
+struct __attribute__((aligned(16))) G2D {
+    float mx, my, opac, depth;
+    float ca, cb, cc;
+    int radius; // 0 = culled
+};
+
+// One per (Gaussian, tile) pair that contributes at least one weight.  mask[q] bit l <=> pixel q*64+l of the tile
+// (row-major 16x16) has a weight; the popc(mask[q]) weights of quarter q are contiguous at wpool[woff[q]..].
+struct __attribute__((aligned(64))) Header {
+    u32 gid;
+    u32 woff[4];
+    u32 pad[3];
+    u64 mask[4];
+};
+static_assert(sizeof(Header) == 64, "header is one 64-B line");
+
+// Mirrors gwbp_stats (include/gwbp.h) field for field.
+struct Counters {
+    u64 n_pairs;
+    u32 n_isect;
+    u32 n_visible;
+    u32 n_headers;
+    u32 pool_head;
+    u32 overflow;
+    u32 reserved;
+};
+static_assert(sizeof(Counters) == sizeof(gwbp_stats), "Counters must mirror gwbp_stats");
+
+struct Layout {
+    size_t total;
+    size_t counters, g2d, rect, touched, blocksums, keys[2], vals[2], hist, digit_total, tile_offsets, hdr_count,
+        headers, wpool;
+    int64_t n, isect_cap, pair_cap;
+    int max_tiles, n_scan_blocks, n_sort_blocks;
+};
+
+struct Ws {
+    Counters *counters;
+    G2D *g2d;
+    uint2 *rect; // x = xmin | xmax<<16, y = ymin | ymax<<16
+    u32 *touched;
+    u32 *blocksums;
+    u64 *keys[2];
+    u32 *vals[2];
+    u32 *hist;
+    u32 *digit_total;
+    u32 *tile_offsets;
+    u32 *hdr_count;
+    Header *headers;
+    float *wpool;
+};
+
+int make_layout(const gwbp_caps *caps, Layout *L);
+int bind_workspace(const gwbp_caps *caps, void *ws, size_t bytes, Layout *L, Ws *W);
+int set_error(int code, const char *fmt, ...);
+int check_hip(hipError_t e, const char *what);
+
+struct ViewDev { // per-launch copy of gwbp_view (kernel argument, 128 B)
+    float R[9];
+    float t[3];
+    float fx, fy, cx, cy;
+    int W, H, tile_w, tile_h;
+    float near_plane, far_plane, eps2d, radius_clip;
+};
+int make_view(const gwbp_view *v, const gwbp_caps *caps, ViewDev *out);
+
+inline int sort_passes(int n_tiles)
+{
+    int tile_bits = 0;
+    while ((1 << tile_bits) < n_tiles)
+        ++tile_bits;
+    return (32 + tile_bits + 7) / 8;
+}
+
+// stage launchers (one per .hip file)
+int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *means, const float *quats,
+                   const float *scales, const float *opac, int32_t *radii, float *means2d, float *depths,
+                   float *conics, hipStream_t s);
+int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *isect_ids, int32_t *flatten_ids,
+                    int32_t *tile_offsets, hipStream_t s);
+int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, hipStream_t s);
+int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
+                   int64_t fs_c, int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s);
+int launch_render(const Layout &L, const Ws &W, const ViewDev &V, const float *colors, int D, float *out,
+                  hipStream_t s);
+int launch_finalize(int64_t N, int D, const float *F, const float *d, float *out, hipStream_t s);
+int launch_dump_pairs(const Layout &L, const Ws &W, const ViewDev &V, int64_t cap, int32_t *gid, int32_t *pix,
+                      float *w, u64 *n_dev, hipStream_t s);
+int launch_accum_stats(const Ws &W, gwbp_stats *accum, hipStream_t s);
+
+// ---- device helpers -----------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float dot3f(float a0, float a1, float a2, float b0, float b1, float b2)
+{
+    return __builtin_fmaf(a2, b2, __builtin_fmaf(a1, b1, a0 * b0));
+}
+
+// exp(x), x <= 0: ln2 hi/lo range reduction, degree-7 Taylor (Horner, fma), exponent added to the bit pattern.
+// Deterministic (no v_exp_f32), so weights do not depend on a transcendental unit; ~12 VALU ops.
+__device__ __forceinline__ float exp_neg(float x)
+{
+    x = __builtin_fmaxf(x, -80.0f);
+    const float t = x * 0x1.715476p+0f;
+    const float n = __builtin_rintf(t);
+    float r = __builtin_fmaf(n, -0x1.62e4p-1f, x);
+    r = __builtin_fmaf(n, -0x1.7f7d1cp-20f, r);
+    float p = 0x1.a01a02p-13f;
+    p = __builtin_fmaf(p, r, 0x1.6c16c2p-10f);
+    p = __builtin_fmaf(p, r, 0x1.111112p-7f);
+    p = __builtin_fmaf(p, r, 0x1.555556p-5f);
+    p = __builtin_fmaf(p, r, 0x1.555556p-3f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    return __int_as_float(__float_as_int(p) + (((int)n) << 23));
+}
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u32 mbcnt(u64 mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+__device__ __forceinline__ u32 uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 uniform64(u64 v)
+{
+    return ((u64)uniform((u32)(v >> 32)) << 32) | uniform((u32)v);
+}
+#endif
+
+} // namespace gwbp

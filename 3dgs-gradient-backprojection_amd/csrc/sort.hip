@@ -1,0 +1,241 @@
+// sort.hip -- stable LSD radix sort of the (tile_id << 32 | depth_bits, gaussian_id) intersection pairs and the
+// per-tile offset table.
+//
+// Replaces cub::DeviceRadixSort::SortPairs + isect_offset_encode inside gsplat 1.4.0's rasterization().
+// The number of pairs n lives in device memory (Counters::n_isect), so every kernel is launched for the caller's
+// capacity and idle blocks exit at once: no host read-back between projection and blend.
+//
+// Per 8-bit pass: (1) k_hist   - per-block digit histogram, hist[digit][block]
+//                 (2) k_scan   - one workgroup per digit: exclusive scan over blocks + digit total
+//                 (3) k_radix_scatter- wave-striped stable ranking (ballot "match" per digit, per-wave LDS counters),
+//                                keys/values kept in registers between ranking and scatter.
+// Only bits [0, 32 + tile_bits) are sorted (6 passes at 1600x1060).
+#include "gwbp_dev.h"
+
+namespace gwbp {
+
+constexpr int kSortThreads = 256;
+constexpr int kItemsPerThread = kSortItems / kSortThreads; // 16
+constexpr int kWaves = kSortThreads / 64;
+constexpr int kWaveItems = kSortItems / kWaves; // 1024 keys per wave segment
+
+__global__ __launch_bounds__(kSortThreads) void k_hist(const u64 *__restrict__ keys,
+                                                       const Counters *__restrict__ ctr, int shift, int nblk,
+                                                       u32 *__restrict__ hist)
+{
+    const u32 n = ctr->n_isect;
+    const u32 base = blockIdx.x * (u32)kSortItems;
+    __shared__ u32 s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    if (base < n) {
+#pragma unroll 4
+        for (int it = 0; it < kItemsPerThread; ++it) {
+            const u32 idx = base + it * kSortThreads + threadIdx.x;
+            if (idx < n)
+                atomicAdd(&s_h[(u32)(keys[idx] >> shift) & 0xFFu], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_h[threadIdx.x];
+}
+
+// block d: exclusive scan of hist[d][0..nblk) in place, digit_total[d] = sum
+__global__ __launch_bounds__(256) void k_scan(int nblk, u32 *__restrict__ hist, u32 *__restrict__ digit_total)
+{
+    u32 *row = hist + (size_t)blockIdx.x * nblk;
+    __shared__ u32 s_wave[4];
+    __shared__ u32 s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 256) {
+        const int i = base + threadIdx.x;
+        const u32 v = (i < nblk) ? row[i] : 0u;
+        u32 incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(incl, o, 64);
+            if (lane >= o)
+                incl += t;
+        }
+        if (lane == 63)
+            s_wave[wave] = incl;
+        __syncthreads();
+        u32 woff = 0;
+        for (int w = 0; w < wave; ++w)
+            woff += s_wave[w];
+        const u32 carry = s_carry;
+        if (i < nblk)
+            row[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255)
+            s_carry = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        digit_total[blockIdx.x] = s_carry;
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u64 *__restrict__ keys_in,
+                                                          const u32 *__restrict__ vals_in,
+                                                          u64 *__restrict__ keys_out, u32 *__restrict__ vals_out,
+                                                          const Counters *__restrict__ ctr, int shift, int nblk,
+                                                          const u32 *__restrict__ hist,
+                                                          const u32 *__restrict__ digit_total)
+{
+    const u32 n = ctr->n_isect;
+    const u32 base = blockIdx.x * (u32)kSortItems;
+    if (base >= n)
+        return;
+    __shared__ u32 s_cnt[kWaves][256]; // per-wave running digit counters, then per-wave bases
+    __shared__ u32 s_start[256];       // global start of each digit (exclusive scan of digit_total)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w)
+        s_cnt[w][threadIdx.x] = 0;
+    { // exclusive scan of the 256 digit totals
+        const u32 v = digit_total[threadIdx.x];
+        u32 incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(incl, o, 64);
+            if (lane >= o)
+                incl += t;
+        }
+        __shared__ u32 s_w[kWaves];
+        if (lane == 63)
+            s_w[wave] = incl;
+        __syncthreads();
+        u32 woff = 0;
+        for (int w = 0; w < wave; ++w)
+            woff += s_w[w];
+        s_start[threadIdx.x] = woff + incl - v;
+    }
+    __syncthreads();
+
+    u64 key[kItemsPerThread];
+    u32 val[kItemsPerThread];
+    u32 rank[kItemsPerThread];
+    const u32 seg = base + wave * (u32)kWaveItems;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int it = 0; it < kItemsPerThread; ++it) {
+        const u32 idx = seg + it * 64 + lane;
+        const bool valid = idx < n;
+        key[it] = valid ? keys_in[idx] : ~0ull;
+        val[it] = valid ? vals_in[idx] : 0u;
+        const u32 dg = (u32)(key[it] >> shift) & 0xFFu;
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (dg >> b) & 1u;
+            const u64 m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        u32 old = 0;
+        const int leader = valid ? (__ffsll((long long)peers) - 1) : 0;
+        if (valid && lane == leader) {
+            old = s_cnt[wave][dg];
+            s_cnt[wave][dg] = old + (u32)__popcll(peers);
+        }
+        old = __shfl(old, leader, 64);
+        rank[it] = old + (u32)__popcll(peers & lt);
+    }
+    __syncthreads();
+    { // thread = digit: turn per-wave counts into global bases
+        const u32 d = threadIdx.x;
+        u32 run = s_start[d] + hist[(size_t)d * nblk + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const u32 c = s_cnt[w][d];
+            s_cnt[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kItemsPerThread; ++it) {
+        const u32 idx = seg + it * 64 + lane;
+        if (idx < n) {
+            const u32 dg = (u32)(key[it] >> shift) & 0xFFu;
+            const u32 pos = s_cnt[wave][dg] + rank[it];
+            keys_out[pos] = key[it];
+            vals_out[pos] = val[it];
+        }
+    }
+}
+
+// isect_offset_encode: offsets[t] = first index whose tile >= t; offsets[n_tiles] = n.
+__global__ __launch_bounds__(256) void k_tile_offsets(const u64 *__restrict__ keys,
+                                                      const Counters *__restrict__ ctr, int n_tiles,
+                                                      u32 *__restrict__ offsets)
+{
+    const u32 n = ctr->n_isect;
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (n == 0) {
+        for (u32 t = i; t <= (u32)n_tiles; t += gridDim.x * 256u)
+            offsets[t] = 0;
+        return;
+    }
+    if (i >= n)
+        return;
+    const int t = (int)(keys[i] >> 32);
+    const int tp = (i == 0) ? -1 : (int)(keys[i - 1] >> 32);
+    for (int tt = tp + 1; tt <= t; ++tt)
+        offsets[tt] = i;
+    if (i == n - 1)
+        for (int tt = t + 1; tt <= n_tiles; ++tt)
+            offsets[tt] = n;
+}
+
+__global__ void k_export_sorted(const u64 *__restrict__ keys, const u32 *__restrict__ vals,
+                                const Counters *__restrict__ ctr, int64_t cap, int64_t *__restrict__ o_keys,
+                                int32_t *__restrict__ o_vals)
+{
+    const u32 n = ctr->n_isect;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool in = i < (int64_t)n;
+        if (o_keys)
+            o_keys[i] = in ? (int64_t)keys[i] : -1;
+        if (o_vals)
+            o_vals[i] = in ? (int32_t)vals[i] : -1;
+    }
+}
+
+__global__ void k_copy_u32(const u32 *__restrict__ src, int32_t *__restrict__ dst, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        dst[i] = (int32_t)src[i];
+}
+
+int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *isect_ids, int32_t *flatten_ids,
+                    int32_t *tile_offsets, hipStream_t s)
+{
+    const int n_tiles = V.tile_w * V.tile_h;
+    const int passes = sort_passes(n_tiles);
+    const int nblk = L.n_sort_blocks;
+    for (int p = 0; p < passes; ++p) {
+        const int in = p & 1, out = in ^ 1;
+        hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(kSortThreads), 0, s, W.keys[in], W.counters, p * 8, nblk, W.hist);
+        hipLaunchKernelGGL(k_scan, dim3(256), dim3(256), 0, s, nblk, W.hist, W.digit_total);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(kSortThreads), 0, s, W.keys[in], W.vals[in], W.keys[out],
+                           W.vals[out], W.counters, p * 8, nblk, W.hist, W.digit_total);
+    }
+    const int fin = passes & 1;
+    const int ob = (int)((L.isect_cap + 255) / 256);
+    hipLaunchKernelGGL(k_tile_offsets, dim3(ob > 0 ? ob : 1), dim3(256), 0, s, W.keys[fin], W.counters, n_tiles,
+                       W.tile_offsets);
+    if (isect_ids || flatten_ids)
+        hipLaunchKernelGGL(k_export_sorted, dim3(1024), dim3(256), 0, s, W.keys[fin], W.vals[fin], W.counters,
+                           L.isect_cap, isect_ids, flatten_ids);
+    if (tile_offsets)
+        hipLaunchKernelGGL(k_copy_u32, dim3((n_tiles + 256) / 256), dim3(256), 0, s, W.tile_offsets, tile_offsets,
+                           n_tiles + 1);
+    return check_hip(hipGetLastError(), "bin_sort launch");
+}
+
+} // namespace gwbp

@@ -1,0 +1,182 @@
+"""Engine: a per-device workspace + thin methods over the C ABI stages (include/gwbp.h).
+
+Everything is enqueued on torch's current HIP stream of the tensors' device; nothing synchronises except
+`stats()` / `dump_pairs()` and the capacity auto-grow in `backproject_view(check=True)`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import Caps, GwbpError, Stats, check, make_view, ptr
+
+TILE = 16
+
+
+def _req(t: torch.Tensor, name: str, shape_tail=None) -> torch.Tensor:
+    if not t.is_cuda:
+        raise GwbpError(f"{name} must be a CUDA/HIP tensor (no CPU fallback exists for this path)")
+    if t.dtype != torch.float32:
+        raise GwbpError(f"{name} must be float32, got {t.dtype}")
+    if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+        raise GwbpError(f"{name} has shape {tuple(t.shape)}, expected [N,{','.join(map(str, shape_tail))}]")
+    return t.contiguous()
+
+
+class Engine:
+    """Workspace sized for (N Gaussians, max WxH, isect_cap, pair_cap) on one device."""
+
+    def __init__(self, n_gaussians: int, max_width: int, max_height: int, device=None,
+                 isect_cap: Optional[int] = None, pair_cap: Optional[int] = None):
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise GwbpError("Engine needs a HIP device (there is no CPU path)")
+        self.lib = _lib.lib()
+        self.n = int(n_gaussians)
+        self.max_w, self.max_h = int(max_width), int(max_height)
+        # Defaults: ~16 tiles per Gaussian and ~128 weights per pixel; both auto-grow on overflow.
+        self.isect_cap = int(isect_cap or max(1 << 18, 16 * self.n))
+        self.pair_cap = int(pair_cap or max(1 << 20, 128 * self.max_w * self.max_h))
+        self._alloc()
+
+    def _alloc(self):
+        self.caps = Caps(self.n, self.isect_cap, self.pair_cap, self.max_w, self.max_h)
+        nbytes = C.c_size_t(0)
+        check(self.lib.gwbp_workspace_size(C.byref(self.caps), C.byref(nbytes)), "gwbp_workspace_size")
+        self.ws_bytes = int(nbytes.value)
+        self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-self.ws.data_ptr()) % 256
+        self._ws_ptr = C.c_void_p(self.ws.data_ptr() + off)
+
+    def grow(self, stats: Dict[str, int]):
+        """Enlarge whichever capacity overflowed (bit0 = isect, bit1 = pairs) and reallocate."""
+        if stats["overflow"] & 1:
+            self.isect_cap *= 2
+        if stats["overflow"] & 2:
+            self.pair_cap *= 2
+        del self.ws
+        self._alloc()
+
+    # ---- helpers -----------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _args(self):
+        return C.byref(self.caps), self._ws_ptr, C.c_size_t(self.ws_bytes)
+
+    def view(self, viewmat, K, width, height, **kw):
+        return make_view(viewmat, K, int(width), int(height), **kw)
+
+    # ---- stages ------------------------------------------------------------------------------------------
+    def project(self, view, means, quats, scales, opacities, want_outputs=False):
+        means, quats = _req(means, "means", (3,)), _req(quats, "quats", (4,))
+        scales, opacities = _req(scales, "scales", (3,)), _req(opacities, "opacities")
+        if means.shape[0] != self.n:
+            raise GwbpError(f"engine was sized for {self.n} Gaussians, got {means.shape[0]}")
+        out = {}
+        if want_outputs:
+            out = dict(radii=torch.empty(self.n, dtype=torch.int32, device=self.device),
+                       means2d=torch.empty(self.n, 2, device=self.device),
+                       depths=torch.empty(self.n, device=self.device),
+                       conics=torch.empty(self.n, 3, device=self.device))
+        check(self.lib.gwbp_project(*self._args(), C.byref(view), ptr(means), ptr(quats), ptr(scales),
+                                    ptr(opacities), ptr(out.get("radii")), ptr(out.get("means2d")),
+                                    ptr(out.get("depths")), ptr(out.get("conics")), self._stream()), "gwbp_project")
+        return out
+
+    def bin_sort(self, view, want_outputs=False):
+        out = {}
+        if want_outputs:
+            nt = -(-view.width // TILE) * -(-view.height // TILE)
+            out = dict(isect_ids=torch.empty(self.isect_cap, dtype=torch.int64, device=self.device),
+                       flatten_ids=torch.empty(self.isect_cap, dtype=torch.int32, device=self.device),
+                       tile_offsets=torch.empty(nt + 1, dtype=torch.int32, device=self.device))
+        check(self.lib.gwbp_bin_sort(*self._args(), C.byref(view), ptr(out.get("isect_ids")),
+                                     ptr(out.get("flatten_ids")), ptr(out.get("tile_offsets")), self._stream()),
+              "gwbp_bin_sort")
+        return out
+
+    def blend_weights(self, view, want_alphas=False):
+        alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
+        check(self.lib.gwbp_blend_weights(*self._args(), C.byref(view), ptr(alphas), self._stream()),
+              "gwbp_blend_weights")
+        return alphas
+
+    @staticmethod
+    def _feat_strides(feats: torch.Tensor, view) -> Tuple[int, int, int, int]:
+        if feats.dim() != 3 or feats.shape[0] != view.height or feats.shape[1] != view.width:
+            raise GwbpError(f"feature map must be [H,W,D] = [{view.height},{view.width},D], got {tuple(feats.shape)}")
+        if feats.dtype != torch.float32 or not feats.is_cuda:
+            raise GwbpError("feature map must be a float32 HIP tensor")
+        sy, sx, sc = feats.stride()
+        if min(sy, sx, sc) < 0:
+            raise GwbpError("negative feature-map strides are not supported")
+        return sy, sx, sc, feats.shape[2]
+
+    def scatter(self, view, feats, F, d, scale_f=1.0, scale_d=1.0):
+        sy, sx, sc, D = self._feat_strides(feats, view)
+        self._check_acc(F, d, D)
+        check(self.lib.gwbp_scatter(*self._args(), C.byref(view), ptr(feats), C.c_int64(sy), C.c_int64(sx),
+                                    C.c_int64(sc), D, C.c_float(scale_f), C.c_float(scale_d), ptr(F), ptr(d),
+                                    self._stream()), "gwbp_scatter")
+
+    def render(self, view, colors):
+        colors = _req(colors, "colors")
+        D = colors.shape[1]
+        out = torch.empty(view.height, view.width, D, device=self.device)
+        check(self.lib.gwbp_render(*self._args(), C.byref(view), ptr(colors), D, ptr(out), self._stream()),
+              "gwbp_render")
+        return out
+
+    def _check_acc(self, F, d, D):
+        if F.dtype != torch.float32 or not F.is_cuda or not F.is_contiguous() or tuple(F.shape) != (self.n, D):
+            raise GwbpError(f"F must be a contiguous float32 HIP tensor [{self.n},{D}]")
+        if d is not None and (d.dtype != torch.float32 or not d.is_contiguous() or tuple(d.shape) != (self.n,)):
+            raise GwbpError(f"d must be a contiguous float32 HIP tensor [{self.n}]")
+
+    def backproject_view(self, view, means, quats, scales, opacities, feats, F, d, scale_f=1.0, scale_d=1.0):
+        """Per-view body of create_feature_field_* (backproject.py:115-151), one fused call."""
+        sy, sx, sc, D = self._feat_strides(feats, view)
+        self._check_acc(F, d, D)
+        means, quats = _req(means, "means", (3,)), _req(quats, "quats", (4,))
+        scales, opacities = _req(scales, "scales", (3,)), _req(opacities, "opacities")
+        check(self.lib.gwbp_backproject_view(*self._args(), C.byref(view), ptr(means), ptr(quats), ptr(scales),
+                                             ptr(opacities), ptr(feats), C.c_int64(sy), C.c_int64(sx),
+                                             C.c_int64(sc), D, C.c_float(scale_f), C.c_float(scale_d), ptr(F),
+                                             ptr(d), self._stream()), "gwbp_backproject_view")
+
+    def finalize(self, F, d, out=None):
+        out = torch.empty_like(F) if out is None else out
+        check(self.lib.gwbp_finalize(C.c_int64(F.shape[0]), F.shape[1], ptr(F), ptr(d), ptr(out), self._stream()),
+              "gwbp_finalize")
+        return out
+
+    # ---- counters ----------------------------------------------------------------------------------------
+    def accumulate_stats(self, accum: torch.Tensor):
+        """accum: uint8[32] device tensor holding a gwbp_stats struct (zero-initialised by the caller)."""
+        check(self.lib.gwbp_accumulate_stats(*self._args(), ptr(accum), self._stream()), "gwbp_accumulate_stats")
+
+    def stats(self) -> Dict[str, int]:
+        st = Stats()
+        check(self.lib.gwbp_read_stats(*self._args(), C.byref(st), self._stream()), "gwbp_read_stats")
+        return st.as_dict()
+
+    @staticmethod
+    def decode_stats(accum: torch.Tensor) -> Dict[str, int]:
+        raw = bytes(accum.cpu().numpy().tobytes())
+        return Stats.from_buffer_copy(raw).as_dict()
+
+    def dump_pairs(self, view):
+        st = self.stats()
+        cap = max(int(st["n_pairs"]), 1)
+        gid = torch.empty(cap, dtype=torch.int32, device=self.device)
+        pix = torch.empty(cap, dtype=torch.int32, device=self.device)
+        w = torch.empty(cap, device=self.device)
+        n = C.c_int64(0)
+        check(self.lib.gwbp_dump_pairs(*self._args(), C.byref(view), C.c_int64(cap), ptr(gid), ptr(pix), ptr(w),
+                                       C.byref(n), self._stream()), "gwbp_dump_pairs")
+        k = int(n.value)
+        return gid[:k], pix[:k], w[:k]

@@ -1,0 +1,218 @@
+"""Drop-in for `gsplat.rasterization` as the reference calls it.
+
+Reference call sites: backproject.py:89-100 (SH render), :115-125 / :133-143 (zeros colours, differentiated),
+utils.py:238-249 (keyword viewmats/Ks, 0-d tensor width/height), click_and_segment.py:241-254 ("RGB+D").
+Signature, defaults and return triple follow gsplat 1.4.0.
+
+Forward  = project -> bin/sort -> blend_weights -> render   (all HIP kernels behind the C ABI)
+Backward = scatter with v_render_colors as the feature map: colors.grad[g,:] += sum_p w_g(p) v_render[p,:]
+           -- exactly what backproject.py:127-131 harvests.  Only `colors` receives a gradient (the reference
+           differentiates nothing else on this path); requesting other gradients raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from ._lib import GwbpError
+from .engine import TILE, Engine
+
+_ENGINES: Dict[Tuple, Engine] = {}
+
+
+def get_engine(device, n: int, width: int, height: int) -> Engine:
+    key = (str(device), n, width, height)
+    eng = _ENGINES.get(key)
+    if eng is None:
+        for k in [k for k in _ENGINES if k[0] == key[0]]:  # one live workspace per device
+            del _ENGINES[k]
+        eng = _ENGINES[key] = Engine(n, width, height, device=device)
+        eng.generation = 0
+    return eng
+
+
+def _run_front(eng: Engine, view, means, quats, scales, opacities, want_alphas, want_meta):
+    """project -> sort -> blend with auto-grow of the capacities (one host sync per call: this is the
+    API-compatible path; the fused driver in backproject.py amortises the check)."""
+    while True:
+        proj = eng.project(view, means, quats, scales, opacities, want_outputs=want_meta)
+        bins = eng.bin_sort(view, want_outputs=want_meta)
+        alphas = eng.blend_weights(view, want_alphas=want_alphas)
+        st = eng.stats()
+        if not st["overflow"]:
+            eng.generation += 1
+            return proj, bins, alphas, st
+        eng.grow(st)
+
+
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, colors, means, quats, scales, opacities, viewmat, K, width, height, kw, holder):
+        dev = means.device
+        eng = get_engine(dev, means.shape[0], width, height)
+        view = eng.view(viewmat, K, width, height, **kw)
+        proj, bins, alphas, st = _run_front(eng, view, means, quats, scales, opacities, True, holder is not None)
+        out = eng.render(view, colors.detach())
+        if holder is not None:
+            holder.update(proj=proj, bins=bins, stats=st)
+        ctx.eng, ctx.view, ctx.gen = eng, view, eng.generation
+        ctx.save_for_backward(means, quats, scales, opacities)
+        ctx.shape = colors.shape
+        ctx.mark_non_differentiable(alphas)
+        return out, alphas
+
+    @staticmethod
+    def backward(ctx, g_out, g_alpha):
+        if any(ctx.needs_input_grad[1:7]):
+            raise NotImplementedError("only d/d(colors) is implemented: the reference differentiates nothing else "
+                                      "(backproject.py:67-72,129,147)")
+        eng, view = ctx.eng, ctx.view
+        means, quats, scales, opacities = ctx.saved_tensors
+        if eng.generation != ctx.gen or eng.n != means.shape[0]:
+            # the workspace was reused by another call since forward: rebuild this view's weight store
+            eng = get_engine(means.device, means.shape[0], view.width, view.height)
+            _run_front(eng, view, means, quats, scales, opacities, False, False)
+        v_colors = torch.zeros(ctx.shape, device=means.device, dtype=torch.float32)
+        eng.scatter(view, g_out, v_colors, None)
+        return (v_colors,) + (None,) * 10
+
+
+class LazyMeta(dict):
+    """meta dict of gsplat.rasterization (packed=True layout); the packed index tensors are materialised on
+    first access because building them (nonzero) synchronises the host."""
+
+    def __init__(self, eager, holders, n_cameras):
+        super().__init__(eager)
+        self._h, self._c = holders, n_cameras
+
+    _LAZY = ("camera_ids", "gaussian_ids", "radii", "means2d", "depths", "conics", "opacities", "tiles_per_gauss",
+             "isect_ids", "flatten_ids", "isect_offsets")
+
+    def _build(self):
+        cams, gids, parts = [], [], {k: [] for k in ("radii", "means2d", "depths", "conics")}
+        isect, flat, offs, base = [], [], [], 0
+        for c, h in enumerate(self._h):
+            p, b = h["proj"], h["bins"]
+            vis = torch.nonzero(p["radii"] > 0)[:, 0]
+            cams.append(torch.full_like(vis, c))
+            gids.append(vis)
+            for k in parts:
+                parts[k].append(p[k][vis])
+            n = h["stats"]["n_isect"]
+            remap = torch.full((p["radii"].shape[0],), -1, dtype=torch.int64, device=vis.device)
+            remap[vis] = torch.arange(vis.numel(), device=vis.device) + base
+            isect.append(b["isect_ids"][:n] | (c << 32 + max(1, math.ceil(math.log2(max(2, b["tile_offsets"].numel() - 1))))))
+            flat.append(remap[b["flatten_ids"][:n].long()].to(torch.int32))
+            offs.append(b["tile_offsets"][:-1] + sum(x.numel() for x in flat[:-1]))
+            base += vis.numel()
+        self["camera_ids"], self["gaussian_ids"] = torch.cat(cams), torch.cat(gids)
+        for k in parts:
+            self[k] = torch.cat(parts[k])
+        self["opacities"] = self._opac[self["gaussian_ids"]]
+        self["isect_ids"], self["flatten_ids"] = torch.cat(isect), torch.cat(flat)
+        self["isect_offsets"] = torch.stack(offs).reshape(self._c, self["tile_height"], self["tile_width"])
+        r = self["radii"].to(torch.float32) / TILE
+        m = self["means2d"] / TILE
+        tw, th = self["tile_width"], self["tile_height"]
+        x0 = torch.clamp(torch.floor(m[:, 0] - r), 0, tw)
+        x1 = torch.clamp(torch.ceil(m[:, 0] + r), 0, tw)
+        y0 = torch.clamp(torch.floor(m[:, 1] - r), 0, th)
+        y1 = torch.clamp(torch.ceil(m[:, 1] + r), 0, th)
+        self["tiles_per_gauss"] = ((x1 - x0) * (y1 - y0)).to(torch.int32)
+
+    def __getitem__(self, k):
+        if k in self._LAZY and not dict.__contains__(self, k):
+            self._build()
+        return dict.__getitem__(self, k)
+
+    def __contains__(self, k):
+        return k in self._LAZY or dict.__contains__(self, k)
+
+
+# Real SH basis constants (degree <= 3), as used by every 3DGS implementation.
+_C0 = 0.28209479177387814
+_C1 = 0.4886025119029199
+_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+       1.445305721320277, -0.5900435899266435)
+
+
+def spherical_harmonics(degree: int, dirs: torch.Tensor, coeffs: torch.Tensor) -> torch.Tensor:
+    """[N,K,3] SH coefficients -> [N,3] colours for unit `dirs` (host-side torch plumbing; feeds the 2-D
+    feature network in the reference, backproject.py:89-100 -- outside the measured hot path)."""
+    d = dirs / dirs.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    out = _C0 * coeffs[:, 0]
+    if degree >= 1:
+        out = out + _C1 * (-y * coeffs[:, 1] + z * coeffs[:, 2] - x * coeffs[:, 3])
+    if degree >= 2:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        out = out + _C2[0] * xy * coeffs[:, 4] + _C2[1] * yz * coeffs[:, 5] + _C2[2] * (2 * zz - xx - yy) * coeffs[:, 6] \
+            + _C2[3] * xz * coeffs[:, 7] + _C2[4] * (xx - yy) * coeffs[:, 8]
+        if degree >= 3:
+            out = out + _C3[0] * y * (3 * xx - yy) * coeffs[:, 9] + _C3[1] * xy * z * coeffs[:, 10] \
+                + _C3[2] * y * (4 * zz - xx - yy) * coeffs[:, 11] \
+                + _C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * coeffs[:, 12] \
+                + _C3[4] * x * (4 * zz - xx - yy) * coeffs[:, 13] + _C3[5] * z * (xx - yy) * coeffs[:, 14] \
+                + _C3[6] * x * (xx - 3 * yy) * coeffs[:, 15]
+    return out
+
+
+def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, near_plane: float = 0.01,
+                  far_plane: float = 1e10, radius_clip: float = 0.0, eps2d: float = 0.3,
+                  sh_degree: Optional[int] = None, packed: bool = True, tile_size: int = 16, backgrounds=None,
+                  render_mode: str = "RGB", sparse_grad: bool = False, absgrad: bool = False,
+                  rasterize_mode: str = "classic", channel_chunk: int = 32, distributed: bool = False,
+                  camera_model: str = "pinhole", covars=None, want_meta: bool = True):
+    """Same call signature / defaults / returns as gsplat.rasterization (1.4.0).
+
+    Returns (render_colors [C,H,W,D'], render_alphas [C,H,W,1], meta).  `channel_chunk`, `packed`, `sparse_grad`
+    are accepted for compatibility and have no effect (the kernels are channel-count generic and unpacked).
+    """
+    if tile_size != TILE:
+        raise GwbpError(f"tile_size must be {TILE}: the tile rectangle is part of the numerics")
+    if camera_model != "pinhole" or covars is not None or distributed or absgrad or rasterize_mode != "classic":
+        raise NotImplementedError("only pinhole / classic / single-process rasterization is on the reference's path")
+    if render_mode not in ("RGB", "D", "ED", "RGB+D", "RGB+ED"):
+        raise ValueError(render_mode)
+    if not means.is_cuda:
+        raise GwbpError("rasterization() needs HIP tensors (the reference likewise requires CUDA, backproject.py:314)")
+    width, height = int(width), int(height)  # utils.py:247-248 passes 0-d tensors
+    C_ = viewmats.shape[0]
+    N = means.shape[0]
+    kw = dict(near_plane=near_plane, far_plane=far_plane, eps2d=eps2d, radius_clip=radius_clip)
+
+    outs, alphas, holders = [], [], []
+    for c in range(C_):
+        vm, K = viewmats[c], Ks[c]
+        if sh_degree is not None:
+            # colors is [N,K,3] (or [C,N,K,3]); view-dependent colour + 0.5, clamped at 0 (gsplat semantics)
+            sh = colors if colors.dim() == 3 else colors[c]
+            campos = -(vm[:3, :3].T @ vm[:3, 3])
+            nb = (sh_degree + 1) ** 2
+            cols = torch.clamp_min(spherical_harmonics(sh_degree, means - campos, sh[:, :nb]) + 0.5, 0.0)
+        else:
+            cols = colors if colors.dim() == 2 else colors[c]
+        holder = {} if (want_meta or "D" in render_mode) else None
+        need_depth = render_mode in ("D", "ED", "RGB+D", "RGB+ED")
+        if need_depth:
+            z = (means @ vm[:3, :3].T + vm[:3, 3])[:, 2:3]
+            cols = z if render_mode in ("D", "ED") else torch.cat([cols, z], dim=1)
+        out, alpha = _Rasterize.apply(cols.contiguous(), means, quats, scales, opacities, vm, K, width, height, kw,
+                                      holder)
+        alpha = alpha[..., None]
+        if render_mode in ("ED", "RGB+ED"):
+            out = torch.cat([out[..., :-1], out[..., -1:] / alpha.clamp_min(1e-10)], dim=-1)
+        if backgrounds is not None:
+            out = out + (1.0 - alpha) * backgrounds[c]
+        outs.append(out)
+        alphas.append(alpha)
+        holders.append(holder)
+    tw, th = -(-width // TILE), -(-height // TILE)
+    eager = dict(tile_width=tw, tile_height=th, width=width, height=height, tile_size=TILE, n_cameras=C_)
+    meta = LazyMeta(eager, holders, C_) if want_meta else eager
+    if want_meta:
+        meta._opac = opacities
+    return torch.stack(outs), torch.stack(alphas), meta

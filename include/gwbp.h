@@ -1,0 +1,134 @@
+/*
+ * gwbp.h -- C ABI of libgwbp.so: gradient-weighted feature back-projection on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the one hot path this repository implements.  In the reference
+ * (JojiJoseph/3dgs-gradient-backprojection) the boundary is the Python operator
+ *     gsplat.rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, ...)
+ * called at backproject.py:89,115,133 (and :223,251,271; backproject_compressed.py:102,129,147;
+ * utils.py:238,316,329) followed by autograd backward (backproject.py:129,147).  gsplat's own native
+ * boundary is a pybind11/torch extension taking at::Tensor; the replacement is a plain C ABI:
+ * raw device pointers, sizes, a hipStream_t passed as void*, int status codes, no C++ types, no torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; fp32 arrays are dense row-major
+ *   - the caller owns every buffer, including the workspace; the library allocates nothing persistent and
+ *     keeps no global mutable state except a thread-local last-error string
+ *   - every entry point only ENQUEUES work on `stream` (no host synchronisation) unless documented
+ *   - return value: 0 = ok, <0 = GWBP_E* (invalid argument / workspace too small), >0 = hipError_t
+ *   - quats are (w,x,y,z) and need not be normalised; scales/opacities are post-activation
+ *     (backproject.py:55-57); viewmat is row-major 4x4 world->camera [R|t] (utils.py:215-219);
+ *     K is row-major 3x3
+ *
+ * Thread-safety: re-entrant; one host thread per GPU process is the expected caller.
+ */
+#ifndef GWBP_H
+#define GWBP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GWBP_OK 0
+#define GWBP_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported tile size, ...) */
+#define GWBP_EWORKSPACE (-2) /* workspace smaller than gwbp_workspace_size() reports */
+#define GWBP_EUNSUPPORTED (-3)
+
+#define GWBP_TILE 16 /* gsplat tile_size default; the tile rectangle rule is part of the numerics */
+
+/* Per-view parameters (host struct, passed by pointer, copied at call time). Mirrors the keyword defaults of
+ * gsplat.rasterization(): near_plane=0.01, far_plane=1e10, radius_clip=0.0, eps2d=0.3, tile_size=16. */
+typedef struct gwbp_view {
+    float viewmat[16]; /* row-major world->camera */
+    float K[9];        /* row-major intrinsics */
+    int32_t width, height;
+    float near_plane, far_plane, eps2d, radius_clip;
+} gwbp_view;
+
+/* Capacities the caller chooses for the variable-size intermediates of one view. */
+typedef struct gwbp_caps {
+    int64_t n_gaussians; /* N */
+    int64_t isect_cap;   /* max (Gaussian, tile) intersections per view */
+    int64_t pair_cap;    /* max stored blend weights (floats) per view, incl. page slack */
+    int32_t max_width, max_height;
+} gwbp_caps;
+
+/* Device-resident per-view counters, readable after the stream has drained (gwbp_read_stats). */
+typedef struct gwbp_stats {
+    uint64_t n_pairs;     /* contributing (Gaussian, pixel) pairs = sum over pixels of #weights */
+    uint32_t n_isect;     /* (Gaussian, tile) intersections emitted */
+    uint32_t n_visible;   /* Gaussians surviving projection culling */
+    uint32_t n_headers;   /* (Gaussian, tile) pairs with at least one contributing pixel */
+    uint32_t pool_used;   /* floats of weight pool consumed */
+    uint32_t overflow;    /* bit0: isect_cap exceeded, bit1: pair_cap exceeded -> results of this view invalid */
+    uint32_t reserved;
+} gwbp_stats;
+
+/* Library / build identification ("gfx950;<git-less build tag>"). */
+const char *gwbp_version(void);
+/* Thread-local description of the last non-zero status returned on this thread. */
+const char *gwbp_last_error_string(void);
+
+/* Bytes of workspace needed for the given capacities (256-B aligned sub-buffers). */
+int gwbp_workspace_size(const gwbp_caps *caps, size_t *bytes_host);
+
+/* ---- stage entry points (replace the stages inside gsplat.rasterization) -------------------- */
+
+/* fully_fused_projection + tiles-per-Gaussian count.  Writes the projected table inside the workspace and,
+ * if non-null, user-visible copies: radii[N] int32 (0 = culled), means2d[N,2], depths[N], conics[N,3]. */
+int gwbp_project(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                 const float *means, const float *quats, const float *scales, const float *opacities,
+                 int32_t *radii, float *means2d, float *depths, float *conics, void *stream);
+
+/* isect_tiles + stable radix sort by (tile, depth) + isect_offset_encode.  Optional outputs:
+ * isect_ids[isect_cap] int64 sorted keys, flatten_ids[isect_cap] int32, tile_offsets[tiles+1] int32. */
+int gwbp_bin_sort(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                  int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_offsets, void *stream);
+
+/* rasterize_to_pixels forward, weights only: per tile, front-to-back blend producing the sparse weight store
+ * (w = alpha*T per contributing (Gaussian, pixel)) inside the workspace; alphas[H*W] (= 1 - T) optional. */
+int gwbp_blend_weights(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                       float *alphas, void *stream);
+
+/* What the reference obtains through backward(): F[g,:] += scale_f * sum_p w_g(p) * feats[p,:] and
+ * d[g] += scale_d * sum_p w_g(p)   (backproject.py:127-131,145-150; scale = 1 for .sum(), 1/(H*W*D) and
+ * 1/(H*W*3) for the dino .mean() variant, backproject.py:263,283).  feats is addressed as
+ * feats[y*fs_y + x*fs_x + c*fs_c] (strides in floats; fs_c == 1 is the fast path).  d may be null. */
+int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                 const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c, int32_t D, float scale_f,
+                 float scale_d, float *F, float *d, void *stream);
+
+/* Forward render (what rasterization() returns): out[p,:] = sum_g w_g(p) * colors[g,:], out is [H,W,D]. */
+int gwbp_render(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                const float *colors, int32_t D, float *out, void *stream);
+
+/* ---- fused entry points --------------------------------------------------------------------------------- */
+
+/* project -> bin_sort -> blend_weights -> scatter for one view: the per-view body of
+ * create_feature_field_lseg (backproject.py:115-151) in one call, one blend instead of two. */
+int gwbp_backproject_view(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
+                          const gwbp_view *view_host, const float *means, const float *quats, const float *scales,
+                          const float *opacities, const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c,
+                          int32_t D, float scale_f, float scale_d, float *F, float *d, void *stream);
+
+/* backproject.py:63,166-169: out = normalize(F / (1e-12 + d)), NaN -> 0.  out may alias F. */
+int gwbp_finalize(int64_t N, int32_t D, const float *F, const float *d, float *out, void *stream);
+
+/* Adds this view's counters into `accum` (device, gwbp_stats) -- used by bench/driver to total pairs. */
+int gwbp_accumulate_stats(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, gwbp_stats *accum,
+                          void *stream);
+/* Copies the workspace's counters of the last view to host memory.  SYNCHRONISES `stream`. */
+int gwbp_read_stats(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, gwbp_stats *stats_host,
+                    void *stream);
+
+/* Debug/test: expand the sparse weight store of the last blended view into triples, sorted by nothing in
+ * particular.  gid/pix/w have room for `cap` entries; *n_host receives the count.  SYNCHRONISES. */
+int gwbp_dump_pairs(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                    int64_t cap, int32_t *gid, int32_t *pix, float *w, int64_t *n_host, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GWBP_H */

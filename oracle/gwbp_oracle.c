@@ -1,0 +1,571 @@
+/*
+ * gwbp_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * Plain-C restatement of the gradient-weighted feature back-projection hot path of
+ * JojiJoseph/3dgs-gradient-backprojection:
+ *
+ *   backproject.py:55-63    activations are applied by the caller; accumulators F[N,D], d[N] (eps 1e-12)
+ *   backproject.py:83-86    one pinhole view: viewmat [R|t] world->cam, W = int(2cx), H = int(2cy)
+ *   backproject.py:115-131  F_v[g,:] = d(sum(render*feats))/d(colors[g,:]) = sum_p w_g(p) * feats[p,:]
+ *   backproject.py:133-151  d_v[g]   = d(sum(render))/d(colors0[g,0])      = sum_p w_g(p)
+ *   backproject.py:166-169  out = normalize(F/d), NaN -> 0
+ *
+ * where w_g(p) = alpha_g(p) * T_g(p) is the alpha-compositing weight computed by gsplat==1.4.0's
+ * rasterization() (requirements.txt:1).  gsplat is an un-vendored third-party dependency that is ABSENT
+ * from /root/reference and from this image, and the reference has no tests / golden vectors for this path,
+ * so
+ *
+ *        ***  PARITY UNPINNED  ***
+ *
+ * this file restates gsplat 1.4.0's published algorithm (EWA projection with eps2d = 0.3 blur, 3-sigma
+ * integer radius, 16-px tile rectangle binning, stable (tile, depth) sort, front-to-back blend with the
+ * 1/255, 0.999 and 1e-4 constants) as written down in SURVEY.md section 3.3, anchored on the reference's call
+ * sites listed above.  It is cross-checked in tests/ against (i) an independent float64 numpy formulation,
+ * (ii) a literal torch-autograd restatement of the backproject.py loop (zeros colours + backward()) and
+ * (iii) closed-form known-answer cases.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * Arithmetic contract: every fp32 operation below is individually rounded (build with -ffp-contract=off);
+ * fused multiply-adds appear only where fmaf() is written.  exp() is the deterministic polynomial
+ * orc_exp_neg() so that weights do not depend on a libm.  The HIP kernels follow the same written contract
+ * (DESIGN.md "arithmetic contract"), which lets the parity tests require the per-(Gaussian,pixel) weights to
+ * match bit for bit and reserve the 1e-4 tolerance for summation order.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_OK 0
+#define ORC_EINVAL (-1)
+#define ORC_ENOMEM (-2)
+
+/* gsplat 1.4.0 constants */
+#define ORC_ALPHA_MIN 0x1.010102p-8f   /* 1/255 */
+#define ORC_ALPHA_MAX 0x1.ff7ceep-1f   /* 0.999 */
+#define ORC_T_MIN 0x1.a36e2ep-14f      /* 1e-4 */
+#define ORC_RADIUS_FLOOR 0x1.47ae14p-7f /* 0.01 inside sqrt(max(.,b*b-det)) */
+
+static inline float dot3f(float a0, float a1, float a2, float b0, float b1, float b2)
+{
+    return fmaf(a2, b2, fmaf(a1, b1, a0 * b0));
+}
+
+/* exp(x) for x <= 0: range reduction by ln2 (hi/lo split), degree-7 Taylor in Horner form with fmaf,
+ * exponent added to the bit pattern.  |rel err| < 2^-22. */
+static inline float orc_exp_neg(float x)
+{
+    x = fmaxf(x, -80.0f);
+    float t = x * 0x1.715476p+0f;
+    float n = rintf(t);
+    float r = fmaf(n, -0x1.62e4p-1f, x);
+    r = fmaf(n, -0x1.7f7d1cp-20f, r);
+    float p = 0x1.a01a02p-13f;
+    p = fmaf(p, r, 0x1.6c16c2p-10f);
+    p = fmaf(p, r, 0x1.111112p-7f);
+    p = fmaf(p, r, 0x1.555556p-5f);
+    p = fmaf(p, r, 0x1.555556p-3f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    int32_t bits;
+    memcpy(&bits, &p, 4);
+    bits += ((int32_t)n) << 23;
+    memcpy(&p, &bits, 4);
+    return p;
+}
+
+float orc_exp_neg_export(float x) { return orc_exp_neg(x); }
+
+/* ------------------------------------------------------------------------------------------------
+ * 1. Projection (gsplat fully_fused_projection, pinhole, per Gaussian).  radii[i] == 0 <=> culled.
+ * rect = (tile_min.x, tile_min.y, tile_max.x, tile_max.y), min inclusive, max exclusive.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_project(int64_t N, const float *means, const float *quats, const float *scales,
+                const float *viewmat, const float *K, int W, int H, float near_plane, float far_plane,
+                float eps2d, float radius_clip, int tile_size, float *means2d, float *depths,
+                float *conics, int32_t *radii, int32_t *rect)
+{
+    if (N < 0 || W <= 0 || H <= 0 || tile_size <= 0)
+        return ORC_EINVAL;
+    const float R00 = viewmat[0], R01 = viewmat[1], R02 = viewmat[2], tx_ = viewmat[3];
+    const float R10 = viewmat[4], R11 = viewmat[5], R12 = viewmat[6], ty_ = viewmat[7];
+    const float R20 = viewmat[8], R21 = viewmat[9], R22 = viewmat[10], tz_ = viewmat[11];
+    const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const int tile_w = (W + tile_size - 1) / tile_size, tile_h = (H + tile_size - 1) / tile_size;
+    const float Wf = (float)W, Hf = (float)H;
+    const float tan_fovx = 0.5f * Wf / fx, tan_fovy = 0.5f * Hf / fy;
+    const float lim_x_pos = (Wf - cx) / fx + 0x1.333334p-2f * tan_fovx;
+    const float lim_x_neg = cx / fx + 0x1.333334p-2f * tan_fovx;
+    const float lim_y_pos = (Hf - cy) / fy + 0x1.333334p-2f * tan_fovy;
+    const float lim_y_neg = cy / fy + 0x1.333334p-2f * tan_fovy;
+    const float ts = (float)tile_size;
+
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        radii[i] = 0;
+        rect[4 * i + 0] = rect[4 * i + 1] = rect[4 * i + 2] = rect[4 * i + 3] = 0;
+        means2d[2 * i] = means2d[2 * i + 1] = 0.f;
+        depths[i] = 0.f;
+        conics[3 * i] = conics[3 * i + 1] = conics[3 * i + 2] = 0.f;
+
+        const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+        const float x = dot3f(R00, R01, R02, mx, my, mz) + tx_;
+        const float y = dot3f(R10, R11, R12, mx, my, mz) + ty_;
+        const float z = dot3f(R20, R21, R22, mx, my, mz) + tz_;
+        if (z < near_plane || z > far_plane)
+            continue;
+
+        /* quaternion (w,x,y,z), normalised here: the reference passes raw quats (backproject.py:57) */
+        float qw = quats[4 * i], qx = quats[4 * i + 1], qy = quats[4 * i + 2], qz = quats[4 * i + 3];
+        const float n2 = fmaf(qz, qz, fmaf(qy, qy, fmaf(qx, qx, qw * qw)));
+        const float inv = 1.0f / sqrtf(n2);
+        qw *= inv, qx *= inv, qy *= inv, qz *= inv;
+        const float x2 = qx * qx, y2 = qy * qy, z2 = qz * qz;
+        const float xy = qx * qy, xz = qx * qz, yz = qy * qz;
+        const float wx = qw * qx, wy = qw * qy, wz = qw * qz;
+        /* Rq[r][c] */
+        const float q00 = 1.f - 2.f * (y2 + z2), q01 = 2.f * (xy - wz), q02 = 2.f * (xz + wy);
+        const float q10 = 2.f * (xy + wz), q11 = 1.f - 2.f * (x2 + z2), q12 = 2.f * (yz - wx);
+        const float q20 = 2.f * (xz - wy), q21 = 2.f * (yz + wx), q22 = 1.f - 2.f * (x2 + y2);
+        const float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+        /* M = Rq * diag(s) */
+        const float m00 = q00 * s0, m01 = q01 * s1, m02 = q02 * s2;
+        const float m10 = q10 * s0, m11 = q11 * s1, m12 = q12 * s2;
+        const float m20 = q20 * s0, m21 = q21 * s1, m22 = q22 * s2;
+        /* Sigma = M M^T (symmetric) */
+        const float S00 = dot3f(m00, m01, m02, m00, m01, m02);
+        const float S01 = dot3f(m00, m01, m02, m10, m11, m12);
+        const float S02 = dot3f(m00, m01, m02, m20, m21, m22);
+        const float S11 = dot3f(m10, m11, m12, m10, m11, m12);
+        const float S12 = dot3f(m10, m11, m12, m20, m21, m22);
+        const float S22 = dot3f(m20, m21, m22, m20, m21, m22);
+        /* A = Rv * Sigma */
+        const float A00 = dot3f(R00, R01, R02, S00, S01, S02);
+        const float A01 = dot3f(R00, R01, R02, S01, S11, S12);
+        const float A02 = dot3f(R00, R01, R02, S02, S12, S22);
+        const float A10 = dot3f(R10, R11, R12, S00, S01, S02);
+        const float A11 = dot3f(R10, R11, R12, S01, S11, S12);
+        const float A12 = dot3f(R10, R11, R12, S02, S12, S22);
+        const float A20 = dot3f(R20, R21, R22, S00, S01, S02);
+        const float A21 = dot3f(R20, R21, R22, S01, S11, S12);
+        const float A22 = dot3f(R20, R21, R22, S02, S12, S22);
+        /* Sigma_c = A * Rv^T (6 unique entries) */
+        const float C00 = dot3f(A00, A01, A02, R00, R01, R02);
+        const float C01 = dot3f(A00, A01, A02, R10, R11, R12);
+        const float C02 = dot3f(A00, A01, A02, R20, R21, R22);
+        const float C11 = dot3f(A10, A11, A12, R10, R11, R12);
+        const float C12 = dot3f(A10, A11, A12, R20, R21, R22);
+        const float C22 = dot3f(A20, A21, A22, R20, R21, R22);
+
+        /* perspective projection (gsplat persp_proj) */
+        const float rz = 1.0f / z;
+        const float rz2 = rz * rz;
+        const float txc = z * fminf(lim_x_pos, fmaxf(-lim_x_neg, x * rz));
+        const float tyc = z * fminf(lim_y_pos, fmaxf(-lim_y_neg, y * rz));
+        const float J00 = fx * rz, J02 = -(fx * txc * rz2);
+        const float J11 = fy * rz, J12 = -(fy * tyc * rz2);
+        /* B0 = Sigma_c * j0^T, B1 = Sigma_c * j1^T with j0 = (J00,0,J02), j1 = (0,J11,J12) */
+        const float B00 = fmaf(C02, J02, C00 * J00);
+        const float B02 = fmaf(C22, J02, C02 * J00);
+        const float B10 = fmaf(C02, J12, C01 * J11);
+        const float B11 = fmaf(C12, J12, C11 * J11);
+        const float B12 = fmaf(C22, J12, C12 * J11);
+        float c00 = fmaf(J02, B02, J00 * B00);
+        const float c01 = fmaf(J02, B12, J00 * B10);
+        float c11 = fmaf(J12, B12, J11 * B11);
+        const float u = fmaf(fx, x * rz, cx);
+        const float v = fmaf(fy, y * rz, cy);
+
+        /* blur + inverse */
+        c00 += eps2d;
+        c11 += eps2d;
+        const float det = c00 * c11 - c01 * c01;
+        if (!(det > 0.f))
+            continue;
+        const float inv_det = 1.0f / det;
+        const float b = 0.5f * (c00 + c11);
+        const float v1 = b + sqrtf(fmaxf(ORC_RADIUS_FLOOR, b * b - det));
+        const float radf = ceilf(3.f * sqrtf(v1));
+        if (!(radf > radius_clip) || !(radf < 1.0e9f))
+            continue;
+        if (u + radf <= 0.f || u - radf >= Wf || v + radf <= 0.f || v - radf >= Hf)
+            continue;
+
+        /* tile rectangle (gsplat isect_tiles): min inclusive, max exclusive, clamped to the grid */
+        const float tr = radf / ts, tcx = u / ts, tcy = v / ts;
+        float fminx = floorf(tcx - tr), fminy = floorf(tcy - tr);
+        float fmaxx = ceilf(tcx + tr), fmaxy = ceilf(tcy + tr);
+        const float twf = (float)tile_w, thf = (float)tile_h;
+        fminx = fminf(fmaxf(fminx, 0.f), twf), fmaxx = fminf(fmaxf(fmaxx, 0.f), twf);
+        fminy = fminf(fmaxf(fminy, 0.f), thf), fmaxy = fminf(fmaxf(fmaxy, 0.f), thf);
+
+        means2d[2 * i] = u, means2d[2 * i + 1] = v;
+        depths[i] = z;
+        conics[3 * i] = c11 * inv_det;
+        conics[3 * i + 1] = -c01 * inv_det;
+        conics[3 * i + 2] = c00 * inv_det;
+        radii[i] = (int32_t)radf;
+        rect[4 * i + 0] = (int32_t)fminx, rect[4 * i + 1] = (int32_t)fminy;
+        rect[4 * i + 2] = (int32_t)fmaxx, rect[4 * i + 3] = (int32_t)fmaxy;
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 2. Tile binning + stable sort by (tile_id, depth bits).  Gaussians are emitted in ascending index so
+ * equal keys keep ascending Gaussian index (gsplat: cub stable radix sort of isect_ids / flatten_ids).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t orc_count_isects(int64_t N, const int32_t *radii, const int32_t *rect)
+{
+    int64_t n = 0;
+    for (int64_t i = 0; i < N; ++i)
+        if (radii[i] > 0)
+            n += (int64_t)(rect[4 * i + 2] - rect[4 * i]) * (rect[4 * i + 3] - rect[4 * i + 1]);
+    return n;
+}
+
+static int radix_sort_pairs(int64_t n, uint64_t *keys, int32_t *vals, int key_bits)
+{
+    uint64_t *k2 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
+    int32_t *v2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    int64_t *hist = (int64_t *)malloc(sizeof(int64_t) * 65536);
+    if (!k2 || !v2 || !hist) {
+        free(k2), free(v2), free(hist);
+        return ORC_ENOMEM;
+    }
+    uint64_t *src = keys, *dst = k2;
+    int32_t *vs = vals, *vd = v2;
+    for (int shift = 0; shift < key_bits; shift += 16) {
+        memset(hist, 0, sizeof(int64_t) * 65536);
+        for (int64_t i = 0; i < n; ++i)
+            hist[(src[i] >> shift) & 0xFFFF]++;
+        int64_t run = 0;
+        for (int b = 0; b < 65536; ++b) {
+            int64_t c = hist[b];
+            hist[b] = run;
+            run += c;
+        }
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t pos = hist[(src[i] >> shift) & 0xFFFF]++;
+            dst[pos] = src[i];
+            vd[pos] = vs[i];
+        }
+        uint64_t *tk = src;
+        src = dst, dst = tk;
+        int32_t *tv = vs;
+        vs = vd, vd = tv;
+    }
+    if (src != keys) {
+        memcpy(keys, src, sizeof(uint64_t) * (size_t)n);
+        memcpy(vals, vs, sizeof(int32_t) * (size_t)n);
+    }
+    free(k2), free(v2), free(hist);
+    return ORC_OK;
+}
+
+int orc_bin_sort(int64_t N, const float *depths, const int32_t *radii, const int32_t *rect, int tile_w,
+                 int tile_h, int64_t n_isect, int64_t *isect_ids, int32_t *flatten_ids,
+                 int32_t *tile_offsets /* [tile_h*tile_w + 1] */)
+{
+    int64_t k = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        if (radii[i] <= 0)
+            continue;
+        uint32_t dbits;
+        memcpy(&dbits, &depths[i], 4);
+        for (int ty = rect[4 * i + 1]; ty < rect[4 * i + 3]; ++ty)
+            for (int tx = rect[4 * i]; tx < rect[4 * i + 2]; ++tx) {
+                if (k >= n_isect)
+                    return ORC_EINVAL;
+                isect_ids[k] = (int64_t)(((uint64_t)(ty * tile_w + tx) << 32) | dbits);
+                flatten_ids[k] = (int32_t)i;
+                ++k;
+            }
+    }
+    if (k != n_isect)
+        return ORC_EINVAL;
+    int tile_bits = 0;
+    while ((1 << tile_bits) < tile_w * tile_h)
+        ++tile_bits;
+    int rc = radix_sort_pairs(n_isect, (uint64_t *)isect_ids, flatten_ids, 32 + tile_bits);
+    if (rc)
+        return rc;
+    const int n_tiles = tile_w * tile_h;
+    int64_t j = 0;
+    for (int t = 0; t <= n_tiles; ++t) {
+        while (j < n_isect && (int)((uint64_t)isect_ids[j] >> 32) < t)
+            ++j;
+        tile_offsets[t] = (int32_t)j;
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 3. Blend (gsplat rasterize_to_pixels forward, per pixel, front to back).  Shared by the functions below.
+ * Calls emit(ctx, slot, gid, w) for every contributing (Gaussian, pixel) pair; returns final T.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t gid;
+    int32_t pix; /* y*W + x */
+    float w;
+} orc_pair_t;
+
+typedef struct {
+    orc_pair_t *p;
+    int64_t n, cap;
+} pairvec_t;
+
+static int pv_push(pairvec_t *v, int32_t gid, int32_t pix, float w)
+{
+    if (v->n == v->cap) {
+        int64_t nc = v->cap ? v->cap * 2 : 4096;
+        orc_pair_t *np = (orc_pair_t *)realloc(v->p, sizeof(orc_pair_t) * (size_t)nc);
+        if (!np)
+            return ORC_ENOMEM;
+        v->p = np, v->cap = nc;
+    }
+    v->p[v->n].gid = gid, v->p[v->n].pix = pix, v->p[v->n].w = w;
+    v->n++;
+    return ORC_OK;
+}
+
+/* blend one tile; pairs appended in (pixel row-major within tile, list slot) order */
+static int blend_tile(int tx, int ty, int W, int H, int tile_size, const int32_t *tile_offsets, int tile_w,
+                      const int32_t *flatten_ids, const float *means2d, const float *conics,
+                      const float *opacities, pairvec_t *out, float *alphas)
+{
+    const int t = ty * tile_w + tx;
+    const int32_t beg = tile_offsets[t], end = tile_offsets[t + 1];
+    for (int iy = ty * tile_size; iy < (ty + 1) * tile_size && iy < H; ++iy)
+        for (int ix = tx * tile_size; ix < (tx + 1) * tile_size && ix < W; ++ix) {
+            const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
+            float T = 1.0f;
+            for (int32_t s = beg; s < end; ++s) {
+                const int32_t g = flatten_ids[s];
+                const float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+                const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+                /* sigma = 0.5*(a dx^2 + c dy^2) + b dx dy, written with two fmaf */
+                const float sigma = fmaf(cb * dx, dy, 0.5f * fmaf(ca * dx, dx, (cc * dy) * dy));
+                if (sigma < 0.f)
+                    continue;
+                const float alpha = fminf(ORC_ALPHA_MAX, opacities[g] * orc_exp_neg(-sigma));
+                if (alpha < ORC_ALPHA_MIN)
+                    continue;
+                const float next_T = T * (1.0f - alpha);
+                if (next_T <= ORC_T_MIN)
+                    break; /* this Gaussian is NOT counted */
+                const float w = alpha * T;
+                int rc = pv_push(out, g, iy * W + ix, w);
+                if (rc)
+                    return rc;
+                T = next_T;
+            }
+            if (alphas)
+                alphas[(int64_t)iy * W + ix] = 1.0f - T;
+        }
+    return ORC_OK;
+}
+
+/* Dump all pairs of a view (tile-major).  Call with cap = 0 to count.  Returns count or <0. */
+int64_t orc_blend_pairs(int W, int H, int tile_size, const int32_t *tile_offsets, const int32_t *flatten_ids,
+                        const float *means2d, const float *conics, const float *opacities, int64_t cap,
+                        int32_t *gid, int32_t *pix, float *w, float *alphas)
+{
+    const int tile_w = (W + tile_size - 1) / tile_size, tile_h = (H + tile_size - 1) / tile_size;
+    int64_t n = 0;
+    pairvec_t pv = {0, 0, 0};
+    for (int ty = 0; ty < tile_h; ++ty)
+        for (int tx = 0; tx < tile_w; ++tx) {
+            pv.n = 0;
+            int rc = blend_tile(tx, ty, W, H, tile_size, tile_offsets, tile_w, flatten_ids, means2d,
+                                conics, opacities, &pv, alphas);
+            if (rc) {
+                free(pv.p);
+                return rc;
+            }
+            for (int64_t k = 0; k < pv.n; ++k, ++n)
+                if (n < cap) {
+                    gid[n] = pv.p[k].gid, pix[n] = pv.p[k].pix, w[n] = pv.p[k].w;
+                }
+        }
+    free(pv.p);
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 4. Scatter-accumulate:  F[g,:] += sum_p w * feats[p,:],  d[g] += sum_p w      (backproject.py:127-150)
+ * feats is addressed as feats[y*fs_y + x*fs_x + c*fs_c] (strides in floats).
+ * acc_double = 1: F is double[N*D], d is double[N]   (parity tests; "exact" sums)
+ * acc_double = 0: F is float[N*D],  d is float[N]    (CPU baseline timing; fp32 like the reference)
+ * Threads: phase 1 blends tiles of one tile row in parallel; phase 2 splits the channel range across
+ * threads so that no two threads touch the same F element (bitwise reproducible, no atomics).
+ * ---------------------------------------------------------------------------------------------- */
+int orc_blend_scatter(int64_t N, int D, int W, int H, int tile_size, const int32_t *tile_offsets,
+                      const int32_t *flatten_ids, const float *means2d, const float *conics,
+                      const float *opacities, const float *feats, int64_t fs_y, int64_t fs_x,
+                      int64_t fs_c, int acc_double, void *F, void *d, float *alphas, int64_t *n_pairs,
+                      int nthreads)
+{
+    (void)N;
+    const int tile_w = (W + tile_size - 1) / tile_size, tile_h = (H + tile_size - 1) / tile_size;
+    if (nthreads < 1)
+        nthreads = 1;
+#ifdef _OPENMP
+    omp_set_num_threads(nthreads);
+#else
+    nthreads = 1;
+#endif
+    pairvec_t *pvs = (pairvec_t *)calloc((size_t)tile_w, sizeof(pairvec_t));
+    if (!pvs)
+        return ORC_ENOMEM;
+    int err = 0;
+    int64_t total = 0;
+    for (int ty = 0; ty < tile_h && !err; ++ty) {
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int tx = 0; tx < tile_w; ++tx) {
+            pvs[tx].n = 0;
+            int rc = blend_tile(tx, ty, W, H, tile_size, tile_offsets, tile_w, flatten_ids, means2d, conics,
+                                opacities, &pvs[tx], alphas);
+            if (rc) {
+#pragma omp atomic write
+                err = rc;
+            }
+        }
+        if (err)
+            break;
+        for (int tx = 0; tx < tile_w; ++tx)
+            total += pvs[tx].n;
+#pragma omp parallel num_threads(nthreads)
+        {
+#ifdef _OPENMP
+            const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+            const int tid = 0, nt = 1;
+#endif
+            /* channel slice of this thread, in multiples of 16 channels where possible */
+            const int blocks = (D + 15) / 16;
+            const int b0 = (int)((int64_t)blocks * tid / nt), b1 = (int)((int64_t)blocks * (tid + 1) / nt);
+            const int c0 = b0 * 16, c1 = (b1 * 16 < D) ? b1 * 16 : D;
+            for (int tx = 0; tx < tile_w; ++tx) {
+                const pairvec_t *pv = &pvs[tx];
+                for (int64_t k = 0; k < pv->n; ++k) {
+                    const int32_t g = pv->p[k].gid, pix = pv->p[k].pix;
+                    const float w = pv->p[k].w;
+                    const float *fp = feats + (int64_t)(pix / W) * fs_y + (int64_t)(pix % W) * fs_x;
+                    if (acc_double) {
+                        double *Fg = (double *)F + (int64_t)g * D;
+                        const double wd = (double)w;
+                        if (fs_c == 1)
+                            for (int c = c0; c < c1; ++c)
+                                Fg[c] += wd * (double)fp[c];
+                        else
+                            for (int c = c0; c < c1; ++c)
+                                Fg[c] += wd * (double)fp[(int64_t)c * fs_c];
+                        if (tid == 0)
+                            ((double *)d)[g] += wd;
+                    } else {
+                        float *Fg = (float *)F + (int64_t)g * D;
+                        if (fs_c == 1)
+                            for (int c = c0; c < c1; ++c)
+                                Fg[c] += w * fp[c];
+                        else
+                            for (int c = c0; c < c1; ++c)
+                                Fg[c] += w * fp[(int64_t)c * fs_c];
+                        if (tid == 0)
+                            ((float *)d)[g] += w;
+                    }
+                }
+            }
+        }
+    }
+    for (int tx = 0; tx < tile_w; ++tx)
+        free(pvs[tx].p);
+    free(pvs);
+    if (n_pairs)
+        *n_pairs = total;
+    return err;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 5. Forward render (what rasterization() returns): colours[H,W,D] = sum_g w * colors[g,:], alpha = 1-T.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_render(int64_t N, int D, int W, int H, int tile_size, const int32_t *tile_offsets,
+               const int32_t *flatten_ids, const float *means2d, const float *conics,
+               const float *opacities, const float *colors /* [N,D] */, float *out /* [H,W,D] */,
+               float *alphas /* [H,W] */)
+{
+    (void)N;
+    const int tile_w = (W + tile_size - 1) / tile_size, tile_h = (H + tile_size - 1) / tile_size;
+    int err = 0;
+    memset(out, 0, sizeof(float) * (size_t)H * W * D);
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (int ty = 0; ty < tile_h; ++ty)
+        for (int tx = 0; tx < tile_w; ++tx) {
+            pairvec_t pv = {0, 0, 0};
+            int rc = blend_tile(tx, ty, W, H, tile_size, tile_offsets, tile_w, flatten_ids, means2d, conics,
+                                opacities, &pv, alphas);
+            if (rc) {
+#pragma omp atomic write
+                err = rc;
+            }
+            double *acc = (double *)malloc(sizeof(double) * (size_t)D);
+            int64_t k = 0;
+            while (acc && k < pv.n) {
+                const int32_t pix = pv.p[k].pix;
+                for (int c = 0; c < D; ++c)
+                    acc[c] = 0.0;
+                for (; k < pv.n && pv.p[k].pix == pix; ++k) {
+                    const float *cg = colors + (int64_t)pv.p[k].gid * D;
+                    const double w = (double)pv.p[k].w;
+                    for (int c = 0; c < D; ++c)
+                        acc[c] += w * (double)cg[c];
+                }
+                for (int c = 0; c < D; ++c)
+                    out[(int64_t)pix * D + c] = (float)acc[c];
+            }
+            free(acc);
+            free(pv.p);
+        }
+    return err;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 6. Finalise (backproject.py:63,166-169):  den = 1e-12f + d (fp32);  x = F/den;  x /= ||x||;  NaN -> 0.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_finalize(int64_t N, int D, int acc_double, const void *F, const void *d, float *out)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < N; ++g) {
+        const float dg = acc_double ? (float)((const double *)d)[g] : ((const float *)d)[g];
+        const float den = 1e-12f + dg;
+        double nrm2 = 0.0;
+        for (int c = 0; c < D; ++c) {
+            const float Fc = acc_double ? (float)((const double *)F)[g * D + c] : ((const float *)F)[g * D + c];
+            const float x = Fc / den;
+            out[g * D + c] = x;
+            nrm2 += (double)x * (double)x;
+        }
+        const float nrm = (float)sqrt(nrm2);
+        for (int c = 0; c < D; ++c) {
+            float x = out[g * D + c] / nrm;
+            if (x != x)
+                x = 0.f;
+            out[g * D + c] = x;
+        }
+    }
+    return ORC_OK;
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
