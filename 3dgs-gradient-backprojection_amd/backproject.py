@@ -66,6 +66,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     F = torch.zeros(n, d_out, device=dev, dtype=torch.float32)
     d = torch.zeros(n, device=dev, dtype=torch.float32)
     my_views = list(views) if views is not None else view_shard(viewmats.shape[0], rank, world)
+    vm_host, K_host = viewmats.detach().cpu(), K.detach().cpu()  # one D2H copy, not one per view
     if reduction == "sum":
         sf, sd = 1.0, 1.0
     elif reduction == "mean":
@@ -78,7 +79,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
         accum = torch.zeros(32, dtype=torch.uint8, device=dev)
 
         def view_fn(v, feats):  # noqa: F811
-            view = eng.view(viewmats[v], K, width, height)
+            view = eng.view(vm_host[v], K_host, width, height)
             eng.backproject_view(view, means, quats, scales, opacities, feats, F, d, sf, sd)
             eng.accumulate_stats(accum)
     else:

@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline workload on MI355X.
+
+metric  : Gaussian-pixel-features/sec = sum over timed views of (#contributing (Gaussian, pixel) pairs) x D / time
+workload: BASELINE.json configs[1] ("C2"): 1M synthetic Gaussians, 1600x1060 views, D = 512 feature maps
+step    : one view of the hot path: project -> bin/sort -> blend weights -> scatter-accumulate into F[N,D], d[N]
+          (backproject.py:115-151), inputs resident in HBM.  Views shard over ranks (r, r+R, ...); after the last
+          step the ranks' partial F/d are summed with ONE all-reduce (RCCL over xGMI) inside the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C1|C4|C5] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--pool", type=int, default=4, help="feature maps cycled through (SURVEY.md 8d)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-views", type=int, default=1)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import gsbp_amd
+    from gsbp_amd import synthetic as syn
+
+    cfg = syn.CONFIGS[args.config]
+    N, W, H = cfg.n_gaussians, cfg.width, cfg.height
+    D_in = cfg.feat_dim
+    means, quats, scales, opac = [t.to(dev) for t in syn.activate(syn.make_scene(cfg))]
+    K = syn.intrinsics(cfg)
+    n_views_needed = world * (args.steps + args.warmup)
+    vms = syn.make_cameras(cfg, n_views=max(cfg.n_views, n_views_needed))
+    encoder = syn.make_encoder(cfg).to(dev) if cfg.encoder_dim else None
+    D = cfg.encoder_dim or D_in
+
+    # feature-map pool, generated on device (seeded), L2-normalised over channels like backproject.py:109
+    pool = [syn.make_feature_map(cfg, 1000 * rank + i, device=dev) for i in range(args.pool)]
+    if encoder is not None:  # backproject_compressed.py:127 happens inside the timed step
+        pass
+
+    eng = gsbp_amd.Engine(N, W, H, device=dev)
+    F = torch.zeros(N, D, device=dev)
+    d = torch.zeros(N, device=dev)
+    accum = torch.zeros(32, dtype=torch.uint8, device=dev)
+    my_views = [rank + world * i for i in range(args.steps + args.warmup)]
+    views = [eng.view(vms[v], K, W, H) for v in my_views]
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+
+    def step(i, timed_idx=None):
+        feats = pool[i % args.pool]
+        view = views[i]
+        if encoder is not None:
+            feats = feats @ encoder
+        if timed_idx is None:
+            eng.backproject_view(view, means, quats, scales, opac, feats, F, d)
+            return
+        e = ev[timed_idx]
+        e[0].record()
+        eng.project(view, means, quats, scales, opac)
+        eng.bin_sort(view)
+        e[1].record()
+        eng.blend_weights(view)
+        e[2].record()
+        eng.scatter(view, feats, F, d)
+        e[3].record()
+        eng.accumulate_stats(accum)
+
+    for i in range(args.warmup):
+        step(i)
+    st = eng.stats()
+    if st["overflow"]:
+        eng.grow(st)
+        for i in range(args.warmup):
+            step(i)
+    F.zero_()
+    d.zero_()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k, k)
+    if world > 1:
+        gsbp_amd.reduce_partials(F, d)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    stats = gsbp_amd.Engine.decode_stats(accum)
+    tt = torch.tensor([elapsed, float(stats["n_pairs"]), float(stats["overflow"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        total_pairs, overflow = float(tt[1]), float(tmax[2])
+    else:
+        total_pairs, overflow = float(tt[1]), float(tt[2])
+
+    t_sort = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    t_blend = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    t_scatter = sum(e[2].elapsed_time(e[3]) for e in ev) / args.steps
+
+    if rank == 0:
+        n_vis = stats["n_visible"] / args.steps
+        n_isect = stats["n_isect"] / args.steps
+        n_hdr = stats["n_headers"] / args.steps
+        pairs_view = stats["n_pairs"] / args.steps
+        # algorithmic bytes of ONE scatter launch: feature map read once + RMW of the F rows
+        # and d entries of the Gaussians visible in the view (4HWD + 8 N_vis (D+1))
+        b_scatter = 4.0 * H * W * D + 8.0 * n_vis * (D + 1)
+        b_view = b_scatter + 44.0 * N + 24.0 * n_isect
+        achieved = b_scatter / (t_scatter * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.config, {}).get("scatter_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Gaussian-pixel-features/sec", "value": total_pairs * D / elapsed,
+            "unit": "Gaussian-pixel-features/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.name}: {N} Gaussians, {W}x{H} views, D={D_in}"
+                                   + (f"->{D} (encoder)" if encoder is not None else "")
+                                   + f", {args.steps} views/GPU, view-sharded over {world} GPU(s), one all-reduce",
+                       "views_per_sec": world * args.steps / elapsed, "pairs_per_view": pairs_view,
+                       "n_visible_per_view": n_vis, "n_isect_per_view": n_isect, "n_headers_per_view": n_hdr,
+                       "overflow": overflow,
+                       "stage_ms": {"project+sort": t_sort, "blend_weights": t_blend, "scatter": t_scatter}},
+            "roofline": {"bound": "hbm", "kernel": "k_scatter", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": b_scatter, "launch_ms": t_scatter,
+                         "pipeline_achieved_GBs": b_view / (elapsed / args.steps) / 1e9,
+                         "atomic_added_GBs": n_hdr * (D + 1) * 4.0 / (t_scatter * 1e-3) / 1e9},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder,
+                                               args.cpu_views)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder, n_views):
+    """The oracle (a CPU port of the same algorithm; the reference itself has no CPU rasteriser) timed on this
+    box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    import numpy as np
+    cores = os.cpu_count() or 1
+    h = [t.cpu().numpy() for t in (means, quats, scales, opac)]
+    Fc = np.zeros((cfg.n_gaussians, D), np.float32)
+    dc = np.zeros(cfg.n_gaussians, np.float32)
+    feats = [(p if encoder is None else p @ encoder).cpu().numpy() for p in pool[:n_views]]
+    orc.lib()
+    pairs, t = 0, 0.0
+    for v in range(n_views):
+        t0 = time.perf_counter()
+        info = orc.backproject_view(h[0], h[1], h[2], h[3], vms[v].numpy(), K.numpy(), cfg.width, cfg.height,
+                                    feats[v % len(feats)], Fc, dc, nthreads=cores)
+        t += time.perf_counter() - t0
+        pairs += info["n_pairs"]
+    return {"value": pairs * D / t, "unit": "Gaussian-pixel-features/s", "cores": cores, "kind": "port",
+            "sample": f"{n_views} view(s) of {cfg.name} at full size (N={cfg.n_gaussians}, {cfg.width}x{cfg.height}, "
+                      f"D={D}), oracle/gwbp_oracle.c with OpenMP on all host cores, fp32 accumulators",
+            "seconds": t, "views_per_sec": n_views / t}
+
+
+if __name__ == "__main__":
+    main()
