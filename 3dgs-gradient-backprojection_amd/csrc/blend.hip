@@ -7,11 +7,12 @@
 //
 //   workgroup = one 16x16 tile, 256 threads; wave q owns tile rows 4q..4q+3, lane l -> pixel q*64 + l
 //   per batch of <= 256 list entries: Gaussian records staged in LDS (2 x 16-B broadcast reads per evaluation)
-//   per (Gaussian, wave): mask = ballot(contributes); the popc(mask) weights are written compacted
-//     (lane rank = mbcnt) into a per-wave stream carved from a global pool in pages of kPage floats
+//   per (Gaussian, wave): mask = ballot(contributes); the popc(mask) {w, pixel} entries are written compacted
+//     (lane rank = mbcnt, 8-B stores) into a per-wave stream carved from a global pool in pages of kPage entries,
+//     each list zero-padded to a multiple of 8 entries (= one s_load_dwordx16 in the scatter kernel)
 //   per (Gaussian, tile) with any contribution: one 64-B Header {gid, 4 x woff, 4 x mask}, compacted in list order
 //
-// Store size: 4 B per pair + 64 B per header (C2: ~330 MB + ~116 MB per view), written once, then read by the
+// Store size: 8 B per pair (+ padding) + 64 B per header (C2: ~0.8 GB + ~116 MB per view), written once, then read by the
 // scatter kernel once per 128-channel chunk through L2.
 #include "gwbp_dev.h"
 
@@ -20,7 +21,7 @@ namespace gwbp {
 __global__ __launch_bounds__(256) void k_blend(ViewDev V, const u32 *__restrict__ tile_offsets,
                                                const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
                                                Counters *__restrict__ ctr, Header *__restrict__ headers,
-                                               u32 *__restrict__ hdr_count, float *__restrict__ wpool,
+                                               u32 *__restrict__ hdr_count, WPair *__restrict__ wpool,
                                                u32 pair_cap, float *__restrict__ alphas)
 {
     __shared__ float4 s_a[256]; // mx, my, opac, gid bits
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(256) void k_blend(ViewDev V, const u32 *__restrict_
                 mask = __ballot(valid);
                 if (mask != 0ull) {
                     const u32 cnt = (u32)__popcll(mask);
-                    if (cnt > page_left) {
+                    const u32 padded = (cnt + (kListPad - 1)) & ~(u32)(kListPad - 1);
+                    if (padded > page_left) {
                         u32 old = 0;
                         if (lane == 0)
                             old = atomicAdd(&ctr->pool_head, (u32)kPage);
@@ -98,11 +100,21 @@ __global__ __launch_bounds__(256) void k_blend(ViewDev V, const u32 *__restrict_
                                 atomicOr(&ctr->overflow, 2u);
                         }
                     }
-                    if (!dead && valid)
-                        wpool[page_pos + mbcnt(mask)] = w;
+                    if (!dead) {
+                        if (valid) {
+                            WPair e;
+                            e.w = w, e.pix = (u32)(wave * 64 + lane);
+                            wpool[page_pos + mbcnt(mask)] = e;
+                        }
+                        if ((u32)lane < padded - cnt) { // {0, 0} tail so the scatter loop needs no remainder handling
+                            WPair z;
+                            z.w = 0.f, z.pix = 0u;
+                            wpool[page_pos + cnt + lane] = z;
+                        }
+                    }
                     woff = page_pos;
-                    page_pos += cnt;
-                    page_left -= cnt;
+                    page_pos += padded;
+                    page_left -= padded;
                     npairs += cnt;
                 }
                 wave_active = __ballot(!done) != 0ull;
@@ -134,7 +146,9 @@ __global__ __launch_bounds__(256) void k_blend(ViewDev V, const u32 *__restrict_
             h.gid = (u32)__float_as_int(s_a[threadIdx.x].w);
             h.woff[0] = s_woff[threadIdx.x][0], h.woff[1] = s_woff[threadIdx.x][1];
             h.woff[2] = s_woff[threadIdx.x][2], h.woff[3] = s_woff[threadIdx.x][3];
-            h.pad[0] = h.pad[1] = h.pad[2] = 0;
+            h.counts = (u32)__popcll(m0) | ((u32)__popcll(m1) << 8) | ((u32)__popcll(m2) << 16) |
+                       ((u32)__popcll(m3) << 24);
+            h.pad[0] = h.pad[1] = 0;
             h.mask[0] = m0, h.mask[1] = m1, h.mask[2] = m2, h.mask[3] = m3;
             headers[beg + off] = h;
         }
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(256) void k_blend(ViewDev V, const u32 *__restrict_
 __global__ __launch_bounds__(256) void k_dump_pairs(ViewDev V, const u32 *__restrict__ tile_offsets,
                                                     const u32 *__restrict__ hdr_count,
                                                     const Header *__restrict__ headers,
-                                                    const float *__restrict__ wpool, int64_t cap,
+                                                    const WPair *__restrict__ wpool, int64_t cap,
                                                     int32_t *__restrict__ gid, int32_t *__restrict__ pix,
                                                     float *__restrict__ w, u64 *__restrict__ n_out)
 {
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(256) void k_dump_pairs(ViewDev V, const u32 *__rest
                     const int ix = tx * kTile + (lane & 15), iy = ty * kTile + q * 4 + (lane >> 4);
                     gid[o] = (int32_t)hd.gid;
                     pix[o] = iy * V.W + ix;
-                    w[o] = wpool[hd.woff[q] + r];
+                    w[o] = wpool[hd.woff[q] + r].w;
                 }
             }
         }

@@ -66,7 +66,7 @@ int make_layout(const gwbp_caps *c, Layout *L)
     L->tile_offsets = take((size_t)(L->max_tiles + 1) * sizeof(u32));
     L->hdr_count = take((size_t)L->max_tiles * sizeof(u32));
     L->headers = take((size_t)L->isect_cap * sizeof(Header));
-    L->wpool = take((size_t)L->pair_cap * sizeof(float));
+    L->wpool = take((size_t)L->pair_cap * sizeof(WPair));
     L->total = o;
     return GWBP_OK;
 }
@@ -97,7 +97,7 @@ int bind_workspace(const gwbp_caps *caps, void *ws, size_t bytes, Layout *L, Ws 
     W->tile_offsets = reinterpret_cast<u32 *>(b + L->tile_offsets);
     W->hdr_count = reinterpret_cast<u32 *>(b + L->hdr_count);
     W->headers = reinterpret_cast<Header *>(b + L->headers);
-    W->wpool = reinterpret_cast<float *>(b + L->wpool);
+    W->wpool = reinterpret_cast<WPair *>(b + L->wpool);
     return GWBP_OK;
 }
 

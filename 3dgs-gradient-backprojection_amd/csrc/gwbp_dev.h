@@ -19,7 +19,8 @@ constexpr float kClampMargin = 0x1.333334p-2f; // 0.3 (x/z clamp margin in tan_f
 
 constexpr int kTile = GWBP_TILE;     // 16 x 16 pixels
 constexpr int kTilePix = 256;
-constexpr int kPage = 1024;          // weight-pool page (floats) grabbed per (tile, wave) stream
+constexpr int kPage = 1024;          // weight-pool page (pairs) grabbed per (tile, wave) stream
+constexpr int kListPad = 8;          // every (record, quarter) list is padded to a multiple of 8 pairs
 constexpr int kSortItems = 4096;     // keys per sort block (256 threads x 16)
 constexpr int kScanBlock = 256;      // Gaussians per project/emit block
 
@@ -31,12 +32,22 @@ struct __attribute__((aligned(16))) G2D {
     int radius; // 0 = culled
 };
 
+// One entry of the sparse weight store: w = alpha * T of one (Gaussian, pixel) pair and the pixel's index inside its
+// 16x16 tile (row-major, 0..255).  8 B so that eight entries are one s_load_dwordx16 and {w, pix} is an aligned SGPR pair.
+struct __attribute__((aligned(8))) WPair {
+    float w;
+    u32 pix;
+};
+
 // One per (Gaussian, tile) pair that contributes at least one weight.  mask[q] bit l <=> pixel q*64+l of the tile
-// (row-major 16x16) has a weight; the popc(mask[q]) weights of quarter q are contiguous at wpool[woff[q]..].
+// (row-major 16x16) has a weight; the popc(mask[q]) entries of quarter q are contiguous at wpool[woff[q]..] in
+// ascending pixel order, followed by {0, 0} entries up to the next multiple of kListPad (woff[q] % 8 == 0).
+// counts = cnt0 | cnt1 << 8 | cnt2 << 16 | cnt3 << 24 (cnt <= 64).
 struct __attribute__((aligned(64))) Header {
     u32 gid;
     u32 woff[4];
-    u32 pad[3];
+    u32 counts;
+    u32 pad[2];
     u64 mask[4];
 };
 static_assert(sizeof(Header) == 64, "header is one 64-B line");
@@ -74,7 +85,7 @@ struct Ws {
     u32 *tile_offsets;
     u32 *hdr_count;
     Header *headers;
-    float *wpool;
+    WPair *wpool;
 };
 
 int make_layout(const gwbp_caps *caps, Layout *L);
@@ -108,6 +119,8 @@ int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *ise
 int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, hipStream_t s);
 int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
                    int64_t fs_c, int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s);
+int launch_scatter_full(const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x, int D,
+                        float scale_f, float scale_d, float *F, float *d, hipStream_t s);
 int launch_render(const Layout &L, const Ws &W, const ViewDev &V, const float *colors, int D, float *out,
                   hipStream_t s);
 int launch_finalize(int64_t N, int D, const float *F, const float *d, float *out, hipStream_t s);

@@ -14,6 +14,8 @@
 //     from HBM once and re-read from that XCD's L2
 // Roofline accounting: HBM bytes/view = 4HWD + 8 N_vis (D+1) + weight store; the binding ceiling of this
 // first version is the fp32 atomic rate (~1.3 TB/s of added bytes), see DESIGN.md section 5.
+#include <stdlib.h>
+
 #include "gwbp_dev.h"
 
 namespace gwbp {
@@ -26,9 +28,22 @@ __device__ __forceinline__ float readlane_f(float v, u32 l)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)l));
 }
 
+
+// Pixel list of a quarter mask without scalar bit-scans: lane l with bit l set sends l to lane rank(l) (= number of
+// set bits below l); lanes whose bit is clear fill the tail [cnt, 64) in order.  One full permutation, all lanes
+// active: afterwards lane k < cnt holds the pixel index of the k-th contributing pixel of the quarter.
+__device__ __forceinline__ int pixel_list(u64 m, int lane, u32 cnt)
+{
+    const u32 rank = mbcnt(m);
+    const bool bit = (m >> lane) & 1ull;
+    const u32 dest = bit ? rank : cnt + ((u32)lane - rank);
+    return __builtin_amdgcn_ds_permute((int)(dest << 2), lane);
+}
+__device__ __forceinline__ int readlane_i(int v, u32 l) { return __builtin_amdgcn_readlane(v, (int)l); }
+
 __global__ __launch_bounds__(kScatterThreads) void k_scatter(
     ViewDev V, int n_tiles_pad, int n_chunks, int pitch, const u32 *__restrict__ tile_offsets,
-    const u32 *__restrict__ hdr_count, const Header *__restrict__ headers, const float *__restrict__ wpool,
+    const u32 *__restrict__ hdr_count, const Header *__restrict__ headers, const WPair *__restrict__ wpool,
     const float *__restrict__ feats, int64_t fs_y, int64_t fs_x, int64_t fs_c, int D, float scale_f, float scale_d,
     float *__restrict__ F, float *__restrict__ dsum_out)
 {
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_scatter(
                 const u32 cnt = (u32)__popcll(r.m[q]);
                 const u32 woff = uniform(hp->woff[q]);
                 if ((u32)lane < cnt)
-                    r.wv[q] = wpool[woff + lane];
+                    r.wv[q] = wpool[woff + lane].w;
             }
         }
         return r;
@@ -131,21 +146,17 @@ __global__ __launch_bounds__(kScatterThreads) void k_scatter(
             u64 m = cur.m[q];
             if (m == 0ull)
                 continue;
-            const float wv = cur.wv[q];
+            const u32 cnt = (u32)__popcll(m);
+            const float wv = cur.wv[q]; // lanes >= cnt hold 0
             wacc += wv;
+            const int pv = pixel_list(m, lane, cnt);
             const float *qrow = lrow + q * 64 * pitch;
-            // four pixels per step: four independent LDS reads in flight, padded with (pixel 0, w = 0)
-            for (u32 k = 0; m != 0ull; k += 4) {
-                const int p0 = __builtin_ctzll(m);
-                m &= m - 1;
-                const int p1 = m ? __builtin_ctzll(m) : 0;
-                m &= m - 1;
-                const int p2 = m ? __builtin_ctzll(m) : 0;
-                m &= m - 1;
-                const int p3 = m ? __builtin_ctzll(m) : 0;
-                m &= m - 1;
+            // four pairs per step: independent LDS reads in flight; the tail reads unset pixels with w = 0
+            for (u32 k = 0; k < cnt; k += 4) {
                 const float w0 = readlane_f(wv, k), w1 = readlane_f(wv, k + 1);
                 const float w2 = readlane_f(wv, k + 2), w3 = readlane_f(wv, k + 3);
+                const int p0 = readlane_i(pv, k), p1 = readlane_i(pv, k + 1);
+                const int p2 = readlane_i(pv, k + 2), p3 = readlane_i(pv, k + 3);
                 const float2 f0 = *reinterpret_cast<const float2 *>(qrow + p0 * pitch);
                 const float2 f1 = *reinterpret_cast<const float2 *>(qrow + p1 * pitch);
                 const float2 f2 = *reinterpret_cast<const float2 *>(qrow + p2 * pitch);
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(256) void k_render(ViewDev V, int n_chunks, int pit
                                                 const u32 *__restrict__ tile_offsets,
                                                 const u32 *__restrict__ hdr_count,
                                                 const Header *__restrict__ headers,
-                                                const float *__restrict__ wpool, const float *__restrict__ colors,
+                                                const WPair *__restrict__ wpool, const float *__restrict__ colors,
                                                 int D, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[]; // [256][pitch]
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(256) void k_render(ViewDev V, int n_chunks, int pit
         const u32 gid = uniform(hp->gid);
         const u32 cnt = (u32)__popcll(m);
         const u32 woff = uniform(hp->woff[q]);
-        const float wv = ((u32)lane < cnt) ? wpool[woff + lane] : 0.f;
+        const float wv = ((u32)lane < cnt) ? wpool[woff + lane].w : 0.f;
         const float *cg = colors + (int64_t)gid * D + c0 + 2 * lane;
         const float col0 = c_on0 ? cg[0] : 0.f, col1 = c_on1 ? cg[1] : 0.f;
         u32 k = 0;
@@ -314,9 +325,14 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const float *
             return rc;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_scatter, dim3(n_tiles_pad * n_chunks), dim3(kScatterThreads), lds_bytes, s, V, n_tiles_pad,
-                       n_chunks, pitch, W.tile_offsets, W.hdr_count, W.headers, W.wpool, feats, fs_y, fs_x, fs_c, D,
-                       scale_f, scale_d, F, d);
+    const bool full = (D % kChunk == 0) && fs_c == 1 && (fs_x % 4 == 0) && (fs_y % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(feats) & 15) == 0);
+    if (full)
+        return launch_scatter_full(W, V, feats, fs_y, fs_x, D, scale_f, scale_d, F, d, s);
+    else
+        hipLaunchKernelGGL(k_scatter, dim3(n_tiles_pad * n_chunks), dim3(kScatterThreads), lds_bytes, s, V,
+                           n_tiles_pad, n_chunks, pitch, W.tile_offsets, W.hdr_count, W.headers, W.wpool, feats, fs_y,
+                           fs_x, fs_c, D, scale_f, scale_d, F, d);
     return check_hip(hipGetLastError(), "scatter launch");
 }
 

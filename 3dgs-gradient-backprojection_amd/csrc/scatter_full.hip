@@ -1,0 +1,308 @@
+// scatter_full.hip -- k_scatter_full: the D % 128 == 0, channel-contiguous fast path of the weighted
+// scatter-accumulate (C2/C4/C5-input: D = 512 / 768 / 1024); semantics identical to k_scatter (scatter.hip).
+//
+//   F[g, c0:c0+128] += sum_p w_g(p) * feats[p, c0:c0+128]        (backproject.py:127-131 via colors.grad)
+//
+// workgroup = (16x16 tile, 128-channel chunk), 1024 threads = 16 waves, one workgroup per CU (128 KB LDS):
+//   * the tile's 256 px x 128 ch slab is staged once (eight 16-B loads per thread in flight, then eight LDS writes):
+//     every feature byte is read from HBM exactly once per view
+//   * a wave owns one (Gaussian, tile) record at a time (LDS work counter); the Gaussian is wave-uniform and
+//     lanes = channel pairs (ds_read_b64: conflict-free 512-B rows)
+//   * the record's {w, pixel} entries (up to four quarter lists in the weight store) are FLATTENED: lane s of load j
+//     fetches entry 64j + s with one 8-B load (it computes which quarter list its slot falls in), so a typical record
+//     (45 entries) costs ONE coalesced 512-B load.  The accumulate loop walks the entries in batches of 8 with
+//     compile-time lane selects: per pair 2 v_readlane (w, pixel) + 1 v_lshl_add (LDS address) + 1 ds_read_b64 +
+//     1 v_pk_fma_f32; the next batch's eight LDS reads are issued before the current batch's FMAs.
+//     Measured ceiling of exactly this instruction mix (tools/ubench_scatter.hip, 16 waves/CU): 453 pairs/us/CU
+//     = 2.98 ms per C2 view; ds_read_b64 + v_pk_fma alone: 1.86 ms.
+//   * records are software-pipelined: claim + header scalar loads two records ahead, entry loads one record ahead.
+//     The entry loads are inline asm and awaited with a COUNTED s_waitcnt: vmcnt retires in order and a float atomic
+//     stays counted for ~3000 cycles under load, so the vmcnt(0) hipcc would insert in front of every record's
+//     entries serialised each record behind its predecessor's atomics (first profile: 7.2 ms/view).
+//         [loads(i): 2] [atomics(i-1): 2 F (+1 d)] [loads(i+1): 2]   ->   s_waitcnt vmcnt(4)
+//     Every VMEM instruction in the steady-state loop is unconditional, so 4 is a guaranteed lower bound of the
+//     younger operations (an over-wait is always safe).
+//   * flush: channel pairs are transposed across lanes (ds_bpermute) so each of the two atomic wave-instructions
+//     covers 64 consecutive dwords (256 contiguous bytes: the shape that runs at the full fp32 atomic rate)
+#include <stdlib.h>
+
+#include "gwbp_dev.h"
+
+namespace gwbp {
+
+namespace {
+
+constexpr int kChunk = 128;
+constexpr int kThreads = 1024;
+constexpr int kSlabFloats = kTilePix * kChunk; // 32768 floats = 128 KB
+constexpr size_t kLdsBytes = (size_t)kSlabFloats * 4 + 16;
+
+struct Rec { // wave-uniform (SGPR) description of one (Gaussian, tile) record
+    u32 gid;
+    u32 woff[4];
+    u32 base[4]; // exclusive prefix of the quarter entry counts
+    u32 T;       // entries in the record (1..256)
+};
+
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ u32 readlane_u(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+
+struct EV { // entries 64j .. 64j+63 of a record, one per lane
+    float w;
+    u32 pix;
+};
+__device__ __forceinline__ void issue_e(EV &dst, const WPair *p)
+{
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(*reinterpret_cast<float2 *>(&dst)) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_e(EV (&e)[2])
+{
+    asm volatile("s_waitcnt vmcnt(%2)"
+                 : "+v"(*reinterpret_cast<float2 *>(&e[0])), "+v"(*reinterpret_cast<float2 *>(&e[1]))
+                 : "n"(N)
+                 : "memory");
+}
+
+__global__ __launch_bounds__(kThreads) void k_scatter_full(
+    ViewDev V, int n_chunks, const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
+    const Header *__restrict__ headers, const WPair *__restrict__ wpool, const float *__restrict__ feats,
+    int64_t fs_y, int64_t fs_x, int D, float scale_f, float scale_d, float *__restrict__ F,
+    float *__restrict__ dsum_out, int dbg)
+{
+    constexpr int pitch = kChunk;
+    // dynamic LDS only (no static __shared__ in front of it: the carve base stays 16-B aligned)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    u32 *s_next = reinterpret_cast<u32 *>(lds + kSlabFloats);
+
+    // XCD-aware decode: blocks b and b+8 share an XCD; one tile's chunks get the same b % 8 so the weight store is
+    // pulled from HBM once and re-read from that XCD's L2.
+    const u32 b = blockIdx.x;
+    const u32 x = b & 7u, sidx = b >> 3;
+    const int chunk = (int)(sidx % (u32)n_chunks);
+    const int tile = (int)((sidx / (u32)n_chunks) * 8u + x);
+    if (tile >= V.tile_w * V.tile_h)
+        return;
+    const u32 nh = hdr_count[tile];
+    if (nh == 0)
+        return;
+    const int tx = tile % V.tile_w, ty = tile / V.tile_w;
+    const int c0 = chunk * kChunk;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0)
+        *s_next = 0;
+
+    if (!(dbg & 4)) { // stage the 256 px x 128 ch slab: 32 float4 per pixel row
+        constexpr int vpr = pitch >> 2;
+        constexpr int kIt = kTilePix * vpr / kThreads; // 8
+        float4 vals[kIt];
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int idx = it * kThreads + threadIdx.x;
+            const int p = idx / vpr, v = idx - p * vpr;
+            const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
+            // pixels past the image edge are never referenced by an entry: load a clamped (valid) address instead
+            // of branching, so the eight loads of a thread are all in flight before the first LDS write
+            const int cx_ = min(ix, V.W - 1), cy_ = min(iy, V.H - 1);
+            vals[it] = *reinterpret_cast<const float4 *>(feats + (int64_t)cy_ * fs_y + (int64_t)cx_ * fs_x + c0 + 4 * v);
+        }
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int idx = it * kThreads + threadIdx.x;
+            const int p = idx / vpr, v = idx - p * vpr;
+            *reinterpret_cast<float4 *>(lds + p * pitch + 4 * v) = vals[it];
+        }
+    }
+    __syncthreads();
+
+    const Header *hbase = headers + tile_offsets[tile];
+    const u32 lane_base = (u32)(2 * lane * sizeof(float)); // byte offset of this lane's channel pair inside a row
+    const char *slab = reinterpret_cast<const char *>(lds);
+    const bool want_d = (chunk == 0) && (dsum_out != nullptr);
+
+    auto claim = [&]() -> u32 {
+        u32 h = 0;
+        if (lane == 0)
+            h = atomicAdd(s_next, 1u);
+        return uniform(h);
+    };
+    auto load_rec = [&](u32 h) -> Rec { // scalar loads; an invalid claim re-reads the last header (never processed)
+        const Header *hp = hbase + min(h, nh - 1);
+        Rec r;
+        r.gid = uniform(hp->gid);
+        const u32 counts = uniform(hp->counts);
+        u32 run = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            r.woff[q] = uniform(hp->woff[q]);
+            r.base[q] = run;
+            run += (counts >> (8 * q)) & 0xFFu;
+        }
+        r.T = run;
+        return r;
+    };
+    // slot s of the record's flattened entry stream -> index into the weight pool
+    auto wslot = [&](const Rec &R, u32 s) -> u32 {
+        u32 off = R.woff[0] + s;
+        off = (s >= R.base[1]) ? R.woff[1] + (s - R.base[1]) : off;
+        off = (s >= R.base[2]) ? R.woff[2] + (s - R.base[2]) : off;
+        off = (s >= R.base[3]) ? R.woff[3] + (s - R.base[3]) : off;
+        return off;
+    };
+    auto prefetch = [&](const Rec &R, EV (&e)[2]) { // exactly 2 VMEM loads (slots 0..127, clamped to the last one)
+        const u32 last = R.T ? R.T - 1 : 0u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            issue_e(e[j], wpool + wslot(R, min((u32)(64 * j + lane), last)));
+    };
+
+    float2 acc;
+    // n in 1..64 entries held by lanes 0..n-1 of ev (lanes >= n: w = 0, pix = any valid pixel)
+    auto run_vec = [&](const EV &ev, u32 n) {
+        float2 fa[8], fb[8];
+#define GWBP_ISSUE8(B, f)                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                     \
+        f[j] = *reinterpret_cast<const float2 *>(slab + ((readlane_u(ev.pix, 8 * (B) + j) << 9) + lane_base));
+#define GWBP_FMA8(B, f)                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                     \
+    {                                                                                                                 \
+        const float w = readlane_f(ev.w, 8 * (B) + j);                                                                \
+        acc.x = __builtin_fmaf(w, f[j].x, acc.x);                                                                     \
+        acc.y = __builtin_fmaf(w, f[j].y, acc.y);                                                                     \
+    }
+        GWBP_ISSUE8(0, fa)
+#pragma unroll
+        for (int B = 0; B < 8; B += 2) { // compile-time lane selects; uniform exits
+            const bool m1 = 8u * (B + 1) < n;
+            if (m1) {
+                GWBP_ISSUE8(B + 1, fb)
+            }
+            GWBP_FMA8(B, fa)
+            if (!m1)
+                break;
+            const bool m2 = 8u * (B + 2) < n;
+            if (m2 && B + 2 < 8) {
+                GWBP_ISSUE8((B + 2) & 7, fa)
+            }
+            GWBP_FMA8(B + 1, fb)
+            if (!m2)
+                break;
+        }
+#undef GWBP_ISSUE8
+#undef GWBP_FMA8
+    };
+    auto process = [&](const Rec &R, const EV (&e)[2]) { // exactly 2 (+1 if want_d) VMEM atomics, always
+        acc = make_float2(0.f, 0.f);
+        float wacc = 0.f;
+        if (!(dbg & 2)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if ((u32)(64 * j) >= R.T)
+                    break;
+                const u32 n = min(64u, R.T - 64u * j);
+                EV ev;
+                ev.w = ((u32)lane < n) ? e[j].w : 0.f; // clamped loads: zero the lanes past the list
+                ev.pix = e[j].pix;
+                wacc += ev.w;
+                run_vec(ev, n);
+            }
+            for (u32 j = 2; 64 * j < R.T; ++j) { // rare: more than 128 entries in one (Gaussian, tile) record
+                const u32 n = min(64u, R.T - 64u * j);
+                const WPair wp = wpool[wslot(R, min(64 * j + lane, R.T - 1))];
+                EV ev;
+                ev.w = ((u32)lane < n) ? wp.w : 0.f;
+                ev.pix = wp.pix;
+                wacc += ev.w;
+                run_vec(ev, n);
+            }
+        }
+        const float a0 = acc.x * scale_f, a1 = acc.y * scale_f;
+        float *Fg = F + (int64_t)R.gid * D + c0;
+        { // channels c0 + [0, 64)
+            const int src = lane >> 1;
+            const float a = __shfl(a0, src, 64), bb = __shfl(a1, src, 64);
+            if (!(dbg & 1))
+                atomicAdd(Fg + lane, (lane & 1) ? bb : a);
+        }
+        { // channels c0 + [64, 128)
+            const int src = 32 + (lane >> 1);
+            const float a = __shfl(a0, src, 64), bb = __shfl(a1, src, 64);
+            if (!(dbg & 1))
+                atomicAdd(Fg + 64 + lane, (lane & 1) ? bb : a);
+        }
+        if (want_d) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                wacc += __shfl_xor(wacc, o, 64);
+            if (lane == 0)
+                atomicAdd(dsum_out + R.gid, wacc * scale_d);
+        }
+    };
+
+    EV eA[2], eB[2];
+    u32 h = claim();
+    if (h >= nh)
+        return;
+    Rec Rcur = load_rec(h);
+    prefetch(Rcur, eA);
+    h = claim();
+    bool vnxt = h < nh;
+    Rec Rnxt = load_rec(h);
+
+    // peeled first phase: no atomics issued yet, only loads(1) are younger than loads(0)
+    prefetch(Rnxt, eB);
+    h = claim();
+    bool vnn = h < nh;
+    Rec Rnn = load_rec(h);
+    wait_e<2>(eA);
+    process(Rcur, eA);
+    while (vnxt) {
+        // odd phase: current record's entries in eB; next record loads into eA
+        Rcur = Rnxt, Rnxt = Rnn, vnxt = vnn;
+        prefetch(Rnxt, eA);
+        h = claim();
+        vnn = h < nh;
+        Rnn = load_rec(h);
+        wait_e<4>(eB);
+        process(Rcur, eB);
+        if (!vnxt)
+            break;
+        // even phase: current in eA; next into eB
+        Rcur = Rnxt, Rnxt = Rnn, vnxt = vnn;
+        prefetch(Rnxt, eB);
+        h = claim();
+        vnn = h < nh;
+        Rnn = load_rec(h);
+        wait_e<4>(eA);
+        process(Rcur, eA);
+    }
+}
+
+} // namespace
+
+int launch_scatter_full(const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x, int D,
+                        float scale_f, float scale_d, float *F, float *d, hipStream_t s)
+{
+    const int n_tiles = V.tile_w * V.tile_h;
+    const int n_tiles_pad = (n_tiles + 7) & ~7;
+    const int n_chunks = D / kChunk;
+    static bool attr_done = false; // benign race: idempotent
+    if (!attr_done) {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_full),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes),
+                           "scatter_full LDS attribute");
+        if (rc)
+            return rc;
+        attr_done = true;
+    }
+    const char *ab = getenv("GWBP_ABLATE"); // profiling ablation only (results are invalid when set)
+    hipLaunchKernelGGL(k_scatter_full, dim3(n_tiles_pad * n_chunks), dim3(kThreads), kLdsBytes, s, V, n_chunks,
+                       W.tile_offsets, W.hdr_count, W.headers, W.wpool, feats, fs_y, fs_x, D, scale_f, scale_d, F, d,
+                       ab ? atoi(ab) : 0);
+    return check_hip(hipGetLastError(), "scatter_full launch");
+}
+
+} // namespace gwbp

@@ -1,0 +1,151 @@
+// Microbenchmark of the scatter inner loop variants (per-pair cost on one CU with 16 waves, 128 KB LDS slab).
+// build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -o ubench_scatter ubench_scatter.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+// MODE 0: 2 readlane + lshl_add + ds_read_b64 + pk_fma   (current design)
+// MODE 1: lshl_add + ds_read_b64 + pk_fma with VGPR-held w/pix (no readlane; per-lane values, uniform content)
+// MODE 2: readlanes only (+ trivial use)
+// MODE 3: ds_read_b64 + pk_fma only (address precomputed per lane, fixed)
+// MODE 4: like 0 but w/pix broadcast by ds_bpermute instead of readlane
+// MODE 5: like 0 but b128 reads (4 ch/lane, 2 pk_fma) on a 64 KB half slab
+template <int MODE>
+__global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ wsrc, const int *__restrict__ psrc,
+                                          float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 32768; i += 1024)
+        lds[i] = (float)(i & 255) * 1e-3f;
+    __syncthreads();
+    float wv = wsrc[(wave * 64 + lane) & 1023];
+    int pv = psrc[(wave * 64 + lane) & 1023] & 255;
+    const char *slab = (const char *)lds;
+    const unsigned lane_base = lane * 8;
+    float2 acc = make_float2(0.f, 0.f);
+    float2 acc2 = make_float2(0.f, 0.f);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            float2 f[8];
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int p = rl_i(pv, 8 * b + j);
+                    f[j] = *(const float2 *)(slab + ((p << 9) + lane_base));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float w = rl_f(wv, 8 * b + j);
+                    acc.x = __builtin_fmaf(w, f[j].x, acc.x);
+                    acc.y = __builtin_fmaf(w, f[j].y, acc.y);
+                }
+            } else if (MODE == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int p = (pv + 8 * b + j) & 255;
+                    f[j] = *(const float2 *)(slab + ((p << 9) + lane_base));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc.x = __builtin_fmaf(wv, f[j].x, acc.x);
+                    acc.y = __builtin_fmaf(wv, f[j].y, acc.y);
+                }
+            } else if (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int p = rl_i(pv, 8 * b + j);
+                    const float w = rl_f(wv, 8 * b + j);
+                    acc.x += w;
+                    acc.y += __int_as_float(p);
+                }
+            } else if (MODE == 3) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    f[j] = *(const float2 *)(slab + (((8 * b + j) << 9) + lane_base));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc.x = __builtin_fmaf(wv, f[j].x, acc.x);
+                    acc.y = __builtin_fmaf(wv, f[j].y, acc.y);
+                }
+            } else if (MODE == 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int p = __builtin_amdgcn_ds_bpermute((8 * b + j) << 2, pv);
+                    f[j] = *(const float2 *)(slab + ((p << 9) + lane_base));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float w = __int_as_float(__builtin_amdgcn_ds_bpermute((8 * b + j) << 2, __float_as_int(wv)));
+                    acc.x = __builtin_fmaf(w, f[j].x, acc.x);
+                    acc.y = __builtin_fmaf(w, f[j].y, acc.y);
+                }
+            } else if (MODE == 5) {
+                float4 g[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int p = rl_i(pv, 8 * b + j) & 31;
+                    g[j] = *(const float4 *)(slab + ((p << 10) + lane * 16));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float w = rl_f(wv, 8 * b + j);
+                    acc.x = __builtin_fmaf(w, g[j].x, acc.x);
+                    acc.y = __builtin_fmaf(w, g[j].y, acc.y);
+                    acc2.x = __builtin_fmaf(w, g[j].z, acc2.x);
+                    acc2.y = __builtin_fmaf(w, g[j].w, acc2.y);
+                }
+            }
+        }
+        pv = (pv + 1) & 255; // keep the loop from being hoisted
+    }
+    out[blockIdx.x * 1024 + threadIdx.x] = acc.x + acc.y + acc2.x + acc2.y;
+}
+
+template <int MODE>
+void run(const char *name, int iters, const float *w, const int *p, float *out)
+{
+    CHECK(hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    k<MODE><<<256, 1024, 131072>>>(iters, w, p, out);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    k<MODE><<<256, 1024, 131072>>>(iters, w, p, out);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double pairs_per_cu = (double)iters * 64 * 16; // per CU (16 waves)
+    printf("%-34s %8.3f ms  %6.2f ns/pair/wave  %5.2f pairs/us/CU  -> C2 view (1.35M pair-chunks/CU): %.2f ms\n", name, ms,
+           ms * 1e6 / (iters * 64.0), pairs_per_cu / (ms * 1e3), 1.35e6 / (pairs_per_cu / ms));
+}
+
+int main()
+{
+    float *w, *out;
+    int *p;
+    CHECK(hipMalloc(&w, 4096));
+    CHECK(hipMalloc(&p, 4096));
+    CHECK(hipMalloc(&out, 256 * 1024 * 4));
+    float hw[1024];
+    int hp[1024];
+    for (int i = 0; i < 1024; ++i) hw[i] = 0.001f * (i % 97), hp[i] = (i * 37) & 255;
+    CHECK(hipMemcpy(w, hw, 4096, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(p, hp, 4096, hipMemcpyHostToDevice));
+    const int iters = 2000;
+    run<0>("0 readlane x2 + add + b64 + pkfma", iters, w, p, out);
+    run<1>("1 (no readlane) add + b64 + pkfma", iters, w, p, out);
+    run<2>("2 readlanes only", iters, w, p, out);
+    run<3>("3 b64 + pkfma only", iters, w, p, out);
+    run<4>("4 bpermute x2 + add + b64 + pkfma", iters, w, p, out);
+    run<5>("5 readlane x2 + add + b128 + 2pkfma", iters, w, p, out);
+    return 0;
+}
