@@ -33,7 +33,7 @@ int make_layout(const gwbp_caps *c, Layout *L)
     if (!c || !L)
         return set_error(GWBP_EINVAL, "null caps");
     if (c->n_gaussians < 0 || c->n_gaussians > 0x7FFFFFFFll || c->isect_cap < 1 || c->isect_cap > 0xFFFFF000ll ||
-        c->pair_cap < kPage || c->pair_cap > 0xFFFFF000ll || c->max_width < 1 || c->max_height < 1 ||
+        c->pair_cap < (int64_t)kPage * kShards || c->pair_cap > 0xFFFFF000ll || c->max_width < 1 || c->max_height < 1 ||
         c->max_width > 65535 * kTile || c->max_height > 65535 * kTile)
         return set_error(GWBP_EINVAL, "caps out of range (N=%lld isect_cap=%lld pair_cap=%lld %dx%d)",
                          (long long)c->n_gaussians, (long long)c->isect_cap, (long long)c->pair_cap, c->max_width,
@@ -53,6 +53,7 @@ int make_layout(const gwbp_caps *c, Layout *L)
         return at;
     };
     L->counters = take(sizeof(Counters));
+    L->shards = take((size_t)kShards * 64);
     L->g2d = take((size_t)L->n * sizeof(G2D));
     L->rect = take((size_t)L->n * sizeof(uint2));
     L->touched = take((size_t)L->n * sizeof(u32));
@@ -84,6 +85,7 @@ int bind_workspace(const gwbp_caps *caps, void *ws, size_t bytes, Layout *L, Ws 
         return set_error(GWBP_EWORKSPACE, "workspace too small: have %zu, need %zu", bytes, L->total);
     char *b = static_cast<char *>(ws);
     W->counters = reinterpret_cast<Counters *>(b + L->counters);
+    W->shards = reinterpret_cast<u32 *>(b + L->shards);
     W->g2d = reinterpret_cast<G2D *>(b + L->g2d);
     W->rect = reinterpret_cast<uint2 *>(b + L->rect);
     W->touched = reinterpret_cast<u32 *>(b + L->touched);

@@ -20,6 +20,7 @@ constexpr float kClampMargin = 0x1.333334p-2f; // 0.3 (x/z clamp margin in tan_f
 constexpr int kTile = GWBP_TILE;     // 16 x 16 pixels
 constexpr int kTilePix = 256;
 constexpr int kPage = 1024;          // weight-pool page (pairs) grabbed per (tile, wave) stream
+constexpr int kShards = 32;          // independently counted regions of the weight pool (one head word per 64-B line)
 constexpr int kListPad = 8;          // every (record, quarter) list is padded to a multiple of 8 pairs
 constexpr int kSortItems = 4096;     // keys per sort block (256 threads x 16)
 constexpr int kScanBlock = 256;      // Gaussians per project/emit block
@@ -66,7 +67,7 @@ static_assert(sizeof(Counters) == sizeof(gwbp_stats), "Counters must mirror gwbp
 
 struct Layout {
     size_t total;
-    size_t counters, g2d, rect, touched, blocksums, keys[2], vals[2], hist, digit_total, tile_offsets, hdr_count,
+    size_t counters, shards, g2d, rect, touched, blocksums, keys[2], vals[2], hist, digit_total, tile_offsets, hdr_count,
         headers, wpool;
     int64_t n, isect_cap, pair_cap;
     int max_tiles, n_scan_blocks, n_sort_blocks;
@@ -74,6 +75,7 @@ struct Layout {
 
 struct Ws {
     Counters *counters;
+    u32 *shards; // kShards head words, 16 u32 apart
     G2D *g2d;
     uint2 *rect; // x = xmin | xmax<<16, y = ymin | ymax<<16
     u32 *touched;

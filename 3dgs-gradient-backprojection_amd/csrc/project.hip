@@ -253,7 +253,9 @@ int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *
                    const float *scales, const float *opac, int32_t *radii, float *means2d, float *depths,
                    float *conics, hipStream_t s)
 {
-    int rc = check_hip(hipMemsetAsync(W.counters, 0, sizeof(Counters), s), "memset counters");
+    // counters and the pool shard heads are adjacent sub-buffers: one memset node
+    int rc = check_hip(hipMemsetAsync(W.counters, 0, (size_t)((char *)W.shards - (char *)W.counters) + kShards * 64, s),
+                       "memset counters");
     if (rc)
         return rc;
     if (L.n == 0)

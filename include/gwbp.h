@@ -61,7 +61,7 @@ typedef struct gwbp_stats {
     uint32_t n_isect;     /* (Gaussian, tile) intersections emitted */
     uint32_t n_visible;   /* Gaussians surviving projection culling */
     uint32_t n_headers;   /* (Gaussian, tile) pairs with at least one contributing pixel */
-    uint32_t pool_used;   /* floats of weight pool consumed */
+    uint32_t pool_used;   /* weight-pool entries a uniform shard capacity would need: kShards x fullest shard */
     uint32_t overflow;    /* bit0: isect_cap exceeded, bit1: pair_cap exceeded -> results of this view invalid */
     uint32_t reserved;
 } gwbp_stats;
