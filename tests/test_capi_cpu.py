@@ -1,0 +1,81 @@
+"""No-GPU checks of the C-ABI library: it loads, exports every symbol include/gwbp.h declares, and its pure-host
+entry points (workspace sizing, argument validation, error strings) behave.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import gsbp_amd
+from gsbp_amd import _lib
+
+HDR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "gwbp.h")
+
+
+def declared_symbols():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gwbp_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    gsbp_amd.build()
+    lib = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 13 and set(syms) == set(_lib.EXPORTS)
+    for s in syms:
+        assert getattr(lib, s) is not None
+    assert b"gfx950" in lib.gwbp_version()
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.View) == 16 * 4 + 9 * 4 + 2 * 4 + 4 * 4
+    assert C.sizeof(_lib.Caps) == 8 * 3 + 4 * 2
+    assert C.sizeof(_lib.Stats) == 32
+
+
+def test_workspace_size_and_argument_validation():
+    lib = _lib.lib()
+    n = C.c_size_t(0)
+    caps = _lib.Caps(1_000_000, 16_000_000, 217_088_000, 1600, 1060)
+    assert lib.gwbp_workspace_size(C.byref(caps), C.byref(n)) == 0
+    # g2d 32 B + rect 8 B + touched 4 B per Gaussian; keys/vals double-buffered 24 B + header 64 B per isect; 8 B/pair
+    expect = 1_000_000 * 44 + 16_000_000 * 88 + 217_088_000 * 8
+    assert expect < n.value < expect * 1.02
+    bad = _lib.Caps(-1, 16, 1 << 20, 64, 64)
+    assert lib.gwbp_workspace_size(C.byref(bad), C.byref(n)) == -1
+    assert b"caps out of range" in lib.gwbp_last_error_string()
+    small = _lib.Caps(10, 1 << 16, 1 << 20, 64, 64)
+    view = _lib.View()
+    view.width, view.height = 64, 64
+    view.K[0] = view.K[4] = 50.0
+    # null workspace / too-small workspace are rejected before any HIP call
+    assert lib.gwbp_project(C.byref(small), None, C.c_size_t(0), C.byref(view), None, None, None, None, None, None,
+                            None, None, None) == -1
+    buf = (C.c_char * 4096)()
+    addr = (C.addressof(buf) + 255) & ~255
+    assert lib.gwbp_project(C.byref(small), C.c_void_p(addr), C.c_size_t(1024), C.byref(view), None, None, None, None,
+                            None, None, None, None, None) == -2
+    assert b"workspace too small" in lib.gwbp_last_error_string()
+    assert lib.gwbp_finalize(C.c_int64(-1), 8, None, None, None, None) == -1
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(gsbp_amd.GwbpError):
+        gsbp_amd.Engine(10, 64, 64, device="cpu")
+    z = torch.zeros(4, 3)
+    with pytest.raises(gsbp_amd.GwbpError):
+        gsbp_amd.rasterization(z, torch.zeros(4, 4), z, torch.zeros(4), z, torch.eye(4)[None], torch.eye(3)[None], 64, 64)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.dirname(_lib.__file__)
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle" not in txt.replace("CPU oracle", "").replace("the oracle", "").replace(
+                    "oracle bit", ""), f

@@ -229,3 +229,35 @@ def test_rerun_determinism_bound(dev):
                              d["scales"], d["opac"], feats, F, dd)
         res.append(F.cpu().numpy())
     assert rel_row_err(res[0], res[1]) <= 1e-5
+
+
+def test_hip_path_reproduces_golden_vectors(dev):
+    """tests/golden/g0.npz (committed inputs + expected outputs): projection, sort keys, per-pair weights and the
+    alpha map bit for bit; F, d, out within the north_star tolerance."""
+    import os
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g0.npz")))
+    W0, H0, N, D = 64, 48, 256, 8
+    t = {k: torch.from_numpy(g[k]).to(dev) for k in ("means", "quats", "scales", "opac")}
+    eng = gsbp_amd.Engine(N, W0, H0, device=dev)
+    view = eng.view(torch.from_numpy(g["vms"][0]), torch.from_numpy(g["K"]), W0, H0)
+    proj = eng.project(view, t["means"], t["quats"], t["scales"], t["opac"], want_outputs=True)
+    bins = eng.bin_sort(view, want_outputs=True)
+    alphas = eng.blend_weights(view, want_alphas=True)
+    for k in ("radii", "means2d", "conics", "depths"):
+        assert np.array_equal(proj[k].cpu().numpy().view(np.uint32), g["v0_" + k].view(np.uint32)), k
+    n = int(g["n_isect"][0])
+    assert np.array_equal(bins["isect_ids"][:n].cpu().numpy(), g["v0_isect_ids"])
+    assert np.array_equal(bins["flatten_ids"][:n].cpu().numpy(), g["v0_flatten_ids"])
+    assert np.array_equal(bins["tile_offsets"].cpu().numpy(), g["v0_tile_offsets"])
+    gid, pix, w = eng.dump_pairs(view)
+    k1, w1 = sort_pairs(gid.cpu().numpy(), pix.cpu().numpy(), w.cpu().numpy())
+    k2, w2 = sort_pairs(g["v0_pair_gid"], g["v0_pair_pix"], g["v0_pair_w"])
+    assert np.array_equal(k1, k2) and np.array_equal(w1.view(np.uint32), w2.view(np.uint32))
+    assert np.array_equal(alphas.cpu().numpy().view(np.uint32), g["v0_alphas"].view(np.uint32))
+    out, F, d, st = gsbp_amd.create_feature_field(t["means"], t["quats"], t["scales"], t["opac"],
+                                                   torch.from_numpy(g["vms"]), torch.from_numpy(g["K"]), W0, H0,
+                                                   lambda v: torch.from_numpy(g["feats"][v]).to(dev), D, engine=eng,
+                                                   return_partials=True)
+    assert st["n_pairs"] == int(g["n_pairs"].sum())
+    assert rel_row_err(F.cpu().numpy(), g["F"]) <= TOL and rel_row_err(d.cpu().numpy()[:, None], g["d"][:, None]) <= TOL
+    assert np.abs(out.cpu().numpy() - g["out"]).max() <= TOL

@@ -1,0 +1,93 @@
+"""Host-side logic that needs no GPU: synthetic generators, view sharding, SH basis, reduction semantics."""
+import math
+
+import numpy as np
+import torch
+
+import gsbp_amd
+from gsbp_amd import synthetic as syn
+
+
+def test_configs_mirror_baseline_json():
+    c = syn.CONFIGS
+    assert (c["C1"].n_gaussians, c["C1"].n_views, c["C1"].width, c["C1"].height, c["C1"].feat_dim) == (10_000, 4, 400, 300, 32)
+    assert (c["C2"].n_gaussians, c["C2"].n_views, c["C2"].width, c["C2"].height, c["C2"].feat_dim) == (1_000_000, 200, 1600, 1060, 512)
+    assert (c["C4"].n_gaussians, c["C4"].n_views, c["C4"].feat_dim) == (5_000_000, 300, 768)
+    assert c["C5"].encoder_dim == 16 and c["C5"].feat_dim == 512
+
+
+def test_scene_and_cameras_are_seeded_and_well_formed():
+    cfg = syn.CONFIGS["T1"]
+    a, b = syn.make_scene(cfg), syn.make_scene(cfg)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    means, quats, scales, opac = syn.activate(a)
+    assert quats.shape == (cfg.n_gaussians, 4) and float(scales.min()) > 0 and 0 < float(opac.min()) < float(opac.max()) < 1
+    assert abs(float(quats.norm(dim=1).mean()) - 1.0) > 0.1  # unnormalised on purpose (backproject.py:57)
+    K = syn.intrinsics(cfg)
+    assert int(K[0, 2] * 2) == cfg.width and int(K[1, 2] * 2) == cfg.height  # backproject.py:85-86
+    vms = syn.make_cameras(cfg, n_views=7)
+    R = vms[:, :3, :3]
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(7, 3, 3), atol=1e-5)
+    assert torch.allclose(torch.linalg.det(R), torch.ones(7), atol=1e-5)
+    c = -(R.transpose(1, 2) @ vms[:, :3, 3:])[:, :, 0]  # camera centres
+    assert torch.all((c.norm(dim=1) > 3.1) & (c.norm(dim=1) < 3.9))
+    origin_cam = vms[:, :3, 3]  # world origin in camera coordinates: straight ahead (+z)
+    assert torch.all(origin_cam[:, 2] > 3.0) and float(origin_cam[:, :2].abs().max()) < 1e-4
+    f = syn.make_feature_map(cfg, 3)
+    assert f.shape == (cfg.height, cfg.width, cfg.feat_dim)
+    assert torch.allclose(f.norm(dim=-1), torch.ones(cfg.height, cfg.width), atol=1e-5)
+
+
+def test_view_shard_partitions_all_views():
+    for world in (1, 2, 3, 8):
+        got = sorted(v for r in range(world) for v in syn.view_shard(200, r, world))
+        assert got == list(range(200))
+        sizes = [len(syn.view_shard(200, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_sh_basis_degree0_and_symmetry():
+    n = 32
+    g = torch.Generator().manual_seed(0)
+    dirs = torch.randn(n, 3, generator=g)
+    coeffs = torch.randn(n, 16, 3, generator=g)
+    c0 = gsbp_amd.spherical_harmonics(0, dirs, coeffs[:, :1])
+    assert torch.allclose(c0, 0.28209479177387814 * coeffs[:, 0])
+    # scaling the direction does not change the colour; odd bands flip sign under d -> -d
+    c3 = gsbp_amd.spherical_harmonics(3, dirs, coeffs)
+    assert torch.allclose(c3, gsbp_amd.spherical_harmonics(3, 5.0 * dirs, coeffs), atol=1e-5)
+    only1 = torch.zeros_like(coeffs)
+    only1[:, 1:4] = coeffs[:, 1:4]
+    assert torch.allclose(gsbp_amd.spherical_harmonics(3, dirs, only1), -gsbp_amd.spherical_harmonics(3, -dirs, only1),
+                          atol=1e-6)
+
+
+def test_prune_mask_is_positive_denominator():
+    d = torch.tensor([0.0, 1e-9, 3.0])
+    assert gsbp_amd.prune_mask(d).tolist() == [False, True, True]  # utils.py:257 keeps grads > 0
+
+
+def test_create_feature_field_cpu_injection_matches_direct(orc):
+    """The driver loop (sharding, reduction modes, encoder) exercised on CPU through the view_fn injection point."""
+    cfg = syn.CONFIGS["T0"]
+    means, quats, scales, opac = syn.activate(syn.make_scene(cfg))
+    K, vms = syn.intrinsics(cfg), syn.make_cameras(cfg)
+    feats = [syn.make_feature_map(cfg, v) for v in range(cfg.n_views)]
+    h = [t.numpy() for t in (means, quats, scales, opac)]
+    for reduction in ("sum", "mean"):
+        sf = 1.0 if reduction == "sum" else 1.0 / (cfg.height * cfg.width * cfg.feat_dim)
+        sd = 1.0 if reduction == "sum" else 1.0 / (cfg.height * cfg.width * 3)
+        acc = {}
+
+        def view_fn(v, f, acc=acc):
+            acc.setdefault("F", np.zeros((cfg.n_gaussians, cfg.feat_dim), np.float64))
+            acc.setdefault("d", np.zeros(cfg.n_gaussians, np.float64))
+            orc.backproject_view(*h, vms[v].numpy(), K.numpy(), cfg.width, cfg.height, f.numpy(), acc["F"], acc["d"])
+
+        out = gsbp_amd.create_feature_field(means, quats, scales, opac, vms, K, cfg.width, cfg.height,
+                                            lambda v: feats[v], cfg.feat_dim, reduction=reduction, view_fn=view_fn)
+        assert float(out.abs().max()) == 0.0  # injected view_fn accumulates elsewhere: driver's own F stays zero
+        ref, _, _, _ = orc.backproject_oracle(*h, vms.numpy(), K.numpy(), cfg.width, cfg.height,
+                                              lambda v: feats[v].numpy(), cfg.feat_dim, reduction=reduction)
+        mine = orc.finalize(np.ascontiguousarray(acc["F"] * sf), np.ascontiguousarray(acc["d"] * sd))
+        assert np.abs(mine - ref).max() < 1e-6
