@@ -167,7 +167,7 @@ def main():
                        "n_visible_per_view": n_vis, "n_isect_per_view": n_isect, "n_headers_per_view": n_hdr,
                        "overflow": overflow,
                        "stage_ms": {"project+sort": t_sort, "blend_weights": t_blend, "scatter": t_scatter}},
-            "roofline": {"bound": "hbm", "kernel": "k_scatter", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_scatter_full", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_scatter, "launch_ms": t_scatter,
                          "pipeline_achieved_GBs": b_view / (elapsed / args.steps) / 1e9,
