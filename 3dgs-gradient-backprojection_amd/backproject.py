@@ -44,10 +44,62 @@ def finalize_reference(F: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
     return x
 
 
+class ViewPipeline:
+    """Two-deep software pipeline over views on two HIP streams and two workspaces.
+
+    front(v)   = project -> bin/sort -> blend_weights   (small latency-bound kernels + the 20 KB-LDS blend)
+    scatter(v) = the weighted scatter-accumulate         (one 139 KB-LDS workgroup per CU: 16 of 32 wave slots)
+    front(v+1) runs on a side stream while scatter(v) runs on the caller's stream, so the front kernels fill
+    the wave slots the scatter kernel cannot use.  Events order  front(v) -> scatter(v) -> front(v+2)
+    (workspace reuse).  Nothing synchronises the host.
+    """
+
+    def __init__(self, n_gaussians, width, height, device, engines=None):
+        self.dev = torch.device(device)
+        self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev) for _ in range(2)]
+        self.side = torch.cuda.Stream(device=self.dev)
+        self.ev_front = [torch.cuda.Event() for _ in range(2)]
+        self.ev_done = [torch.cuda.Event() for _ in range(2)]
+        self.accum = torch.zeros(32, dtype=torch.uint8, device=self.dev)
+        self.i_front = 0    # views whose front stage has been enqueued
+        self.i_scatter = 0  # views whose scatter stage has been enqueued
+        self.pending = {}
+
+    def front(self, view, means, quats, scales, opacities):
+        b = self.i_front % 2
+        main = torch.cuda.current_stream(self.dev)
+        if self.i_front < 2:
+            self.side.wait_stream(main)  # inputs produced on the caller's stream
+        else:
+            self.side.wait_event(self.ev_done[b])  # workspace b is free once scatter(i-2) has finished
+        with torch.cuda.stream(self.side):
+            e = self.eng[b]
+            e.project(view, means, quats, scales, opacities)
+            e.bin_sort(view)
+            e.blend_weights(view)
+            self.ev_front[b].record(self.side)
+        self.pending[self.i_front] = view
+        self.i_front += 1
+
+    def scatter(self, feats, F, d, scale_f=1.0, scale_d=1.0):
+        i = self.i_scatter
+        b = i % 2
+        main = torch.cuda.current_stream(self.dev)
+        main.wait_event(self.ev_front[b])
+        e = self.eng[b]
+        e.scatter(self.pending.pop(i), feats, F, d, scale_f, scale_d)
+        e.accumulate_stats(self.accum)
+        self.ev_done[b].record(main)
+        self.i_scatter += 1
+
+    def stats(self):
+        return Engine.decode_stats(self.accum)  # synchronises
+
+
 def create_feature_field(means, quats, scales, opacities, viewmats, K, width: int, height: int,
                          feature_fn: Callable[[int], torch.Tensor], dim: int, reduction: str = "sum",
                          encoder: Optional[torch.Tensor] = None, engine: Optional[Engine] = None,
-                         views: Optional[Sequence[int]] = None, view_fn=None, check_every: int = 0,
+                         views: Optional[Sequence[int]] = None, view_fn=None, pipeline: bool = True,
                          return_partials: bool = False, verbose: bool = False):
     """Build the [N, dim_out] per-Gaussian feature field.
 
@@ -58,6 +110,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     encoder [dim, dim_out]: backproject_compressed.py:127 (feats @ encoder before back-projection).
     views: explicit list of view indices for this rank (default: interleaved shard over the process group).
     view_fn: injection point for the per-view accumulate (tests drive the sharding/reduction logic on CPU).
+    pipeline: overlap the front stages of view v+1 with the scatter of view v (ViewPipeline).
     """
     dist, rank, world = _dist()
     n = means.shape[0]
@@ -74,32 +127,43 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     else:
         raise ValueError(reduction)
 
+    t0 = time.time()
+    stats: Dict[str, int] = {}
     if view_fn is None:
         eng = engine or Engine(n, width, height, device=dev)
-        accum = torch.zeros(32, dtype=torch.uint8, device=dev)
-
-        def view_fn(v, feats):  # noqa: F811
-            view = eng.view(vm_host[v], K_host, width, height)
-            eng.backproject_view(view, means, quats, scales, opacities, feats, F, d, sf, sd)
-            eng.accumulate_stats(accum)
-    else:
-        eng, accum = None, None
-
-    t0 = time.time()
-    for i, v in enumerate(my_views):
-        feats = feature_fn(v)
-        if encoder is not None:
-            feats = feats @ encoder
-        view_fn(v, feats)
-        if eng is not None and check_every and (i + 1) % check_every == 0:
-            st = Engine.decode_stats(accum)
-            if st["overflow"]:
-                raise RuntimeError(f"workspace overflow (flags {st['overflow']}) at view {v}: enlarge isect_cap/pair_cap")
-    stats: Dict[str, int] = {}
-    if eng is not None:
-        stats = Engine.decode_stats(accum)  # synchronises
+        if pipeline and len(my_views) > 1:
+            pipe = ViewPipeline(n, width, height, dev, engines=[eng, Engine(n, width, height, device=dev,
+                                                                            isect_cap=eng.isect_cap,
+                                                                            pair_cap=eng.pair_cap)])
+            views = [eng.view(vm_host[v], K_host, width, height) for v in my_views]
+            pipe.front(views[0], means, quats, scales, opacities)
+            for i, v in enumerate(my_views):
+                if i + 1 < len(my_views):
+                    pipe.front(views[i + 1], means, quats, scales, opacities)
+                feats = feature_fn(v)
+                if encoder is not None:
+                    feats = feats @ encoder
+                pipe.scatter(feats, F, d, sf, sd)
+            stats = pipe.stats()
+        else:
+            accum = torch.zeros(32, dtype=torch.uint8, device=dev)
+            for i, v in enumerate(my_views):
+                feats = feature_fn(v)
+                if encoder is not None:
+                    feats = feats @ encoder
+                view = eng.view(vm_host[v], K_host, width, height)
+                eng.backproject_view(view, means, quats, scales, opacities, feats, F, d, sf, sd)
+                eng.accumulate_stats(accum)
+            stats = Engine.decode_stats(accum)  # synchronises
         if stats["overflow"]:
             raise RuntimeError(f"workspace overflow (flags {stats['overflow']}): enlarge isect_cap/pair_cap and rerun")
+    else:
+        eng = None
+        for v in my_views:
+            feats = feature_fn(v)
+            if encoder is not None:
+                feats = feats @ encoder
+            view_fn(v, feats)
     reduce_partials(F, d)
     out = eng.finalize(F, d) if eng is not None else finalize_reference(F, d)
     if verbose and rank == 0:

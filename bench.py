@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="feature maps cycled through (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=1)
+    ap.add_argument("--serial", action="store_true", help="one stream, no overlap of front(v+1) with scatter(v)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -68,46 +69,69 @@ def main():
 
     # feature-map pool, generated on device (seeded), L2-normalised over channels like backproject.py:109
     pool = [syn.make_feature_map(cfg, 1000 * rank + i, device=dev) for i in range(args.pool)]
-    if encoder is not None:  # backproject_compressed.py:127 happens inside the timed step
-        pass
-
     eng = gsbp_amd.Engine(N, W, H, device=dev)
     F = torch.zeros(N, D, device=dev)
     d = torch.zeros(N, device=dev)
-    accum = torch.zeros(32, dtype=torch.uint8, device=dev)
     my_views = [rank + world * i for i in range(args.steps + args.warmup)]
     views = [eng.view(vms[v], K, W, H) for v in my_views]
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-
-    def step(i, timed_idx=None):
-        feats = pool[i % args.pool]
-        view = views[i]
-        if encoder is not None:
-            feats = feats @ encoder
-        if timed_idx is None:
-            eng.backproject_view(view, means, quats, scales, opac, feats, F, d)
-            return
-        e = ev[timed_idx]
-        e[0].record()
-        eng.project(view, means, quats, scales, opac)
-        eng.bin_sort(view)
-        e[1].record()
-        eng.blend_weights(view)
-        e[2].record()
-        eng.scatter(view, feats, F, d)
-        e[3].record()
-        eng.accumulate_stats(accum)
-
-    for i in range(args.warmup):
-        step(i)
-    st = eng.stats()
-    if st["overflow"]:
+    # capacity check on one untimed view (the timed loop never reads sizes back)
+    while True:
+        eng.backproject_view(views[0], means, quats, scales, opac, pool[0] if encoder is None else pool[0] @ encoder,
+                             F, d)
+        st = eng.stats()
+        if not st["overflow"]:
+            break
         eng.grow(st)
-        for i in range(args.warmup):
-            step(i)
+    eng2 = gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap)
+    pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng, eng2])
+    accum = pipe.accum
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    n_total = args.steps + args.warmup
+
+    def front(i):
+        """project -> bin/sort -> blend of view i on the side stream (overlaps scatter of view i-1)."""
+        k = i - args.warmup
+        if not args.serial:
+            if 0 <= k < args.steps:
+                with torch.cuda.stream(pipe.side):
+                    ev[k][0].record(pipe.side)
+            pipe.front(views[i], means, quats, scales, opac)
+            if 0 <= k < args.steps:
+                with torch.cuda.stream(pipe.side):
+                    ev[k][1].record(pipe.side)
+
+    def scatter(i):
+        k = i - args.warmup
+        feats = pool[i % args.pool]
+        if encoder is not None:
+            feats = feats @ encoder  # backproject_compressed.py:127 happens inside the timed step
+        if args.serial:  # one stream, one workspace: the pre-pipelining schedule
+            eng.project(views[i], means, quats, scales, opac)
+            eng.bin_sort(views[i])
+            eng.blend_weights(views[i])
+            if 0 <= k < args.steps:
+                ev[k][2].record()
+            eng.scatter(views[i], feats, F, d)
+            eng.accumulate_stats(accum)
+            if 0 <= k < args.steps:
+                ev[k][3].record()
+            return
+        if 0 <= k < args.steps:
+            ev[k][2].record()
+        pipe.scatter(feats, F, d)
+        if 0 <= k < args.steps:
+            ev[k][3].record()
+
+    front(0)
+    for i in range(args.warmup):
+        front(i + 1)
+        scatter(i)
+    torch.cuda.synchronize(dev)
     F.zero_()
     d.zero_()
+    accum.zero_()
 
     def barrier():
         if world > 1:
@@ -116,8 +140,10 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k, k)
+    for i in range(args.warmup, n_total):
+        if i + 1 < n_total:
+            front(i + 1)
+        scatter(i)
     if world > 1:
         gsbp_amd.reduce_partials(F, d)
     barrier()
@@ -134,8 +160,9 @@ def main():
     else:
         total_pairs, overflow = float(tt[1]), float(tt[2])
 
-    t_sort = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
-    t_blend = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    # front(k) of the first timed view was enqueued during warm-up; its events are not recorded
+    fr = [e[0].elapsed_time(e[1]) for e in ev[1:]] if (not args.serial and args.steps > 1) else [0.0]
+    t_front = sum(fr) / len(fr)
     t_scatter = sum(e[2].elapsed_time(e[3]) for e in ev) / args.steps
 
     if rank == 0:
@@ -166,7 +193,9 @@ def main():
                        "views_per_sec": world * args.steps / elapsed, "pairs_per_view": pairs_view,
                        "n_visible_per_view": n_vis, "n_isect_per_view": n_isect, "n_headers_per_view": n_hdr,
                        "overflow": overflow,
-                       "stage_ms": {"project+sort": t_sort, "blend_weights": t_blend, "scatter": t_scatter}},
+                       "schedule": "serial" if args.serial else "front(v+1) overlapped with scatter(v) on two streams",
+                       "stage_ms": {"front(project+sort+blend, side stream, overlapped)": t_front,
+                                    "scatter": t_scatter}},
             "roofline": {"bound": "hbm", "kernel": "k_scatter_full", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_scatter, "launch_ms": t_scatter,
