@@ -240,6 +240,31 @@ int gwbp_render(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, 
     return launch_render(L, W, V, colors, D, out, static_cast<hipStream_t>(stream));
 }
 
+int gwbp_render_pixels(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                       const float *colors, int32_t D, float *out, float *alphas, void *stream)
+{
+    Layout L;
+    Ws W;
+    ViewDev V;
+    int rc = bind_workspace(caps, workspace, workspace_bytes, &L, &W);
+    if (rc)
+        return rc;
+    if ((rc = make_view(view_host, caps, &V)))
+        return rc;
+    if (!colors || !out || D < 1 || D > 4)
+        return set_error(GWBP_EINVAL, "render_pixels needs colors, out and 1 <= D <= 4 (got D=%d)", D);
+    return launch_render_px(W, V, colors, D, out, alphas, static_cast<hipStream_t>(stream));
+}
+
+int gwbp_sh_colors(int64_t N, int32_t degree, int32_t K, const float *means, const float *coeffs,
+                   const float *campos_host, float *out, void *stream)
+{
+    if (N < 0 || degree < 0 || degree > 3 || K < (degree + 1) * (degree + 1) || !campos_host ||
+        (N > 0 && (!means || !coeffs || !out)))
+        return set_error(GWBP_EINVAL, "bad sh_colors arguments (N=%lld degree=%d K=%d)", (long long)N, degree, K);
+    return launch_sh_colors(N, degree, K, means, coeffs, campos_host, out, static_cast<hipStream_t>(stream));
+}
+
 int gwbp_backproject_view(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
                           const gwbp_view *view_host, const float *means, const float *quats, const float *scales,
                           const float *opacities, const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c,

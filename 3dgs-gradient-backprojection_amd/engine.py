@@ -131,6 +131,28 @@ class Engine:
               "gwbp_render")
         return out
 
+    def render_pixels(self, view, colors, want_alphas=True):
+        """Pixel-parallel forward render for 1..4 channels; needs project + bin_sort of `view` (not the weight store)."""
+        colors = _req(colors, "colors")
+        D = colors.shape[1]
+        out = torch.empty(view.height, view.width, D, device=self.device)
+        alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
+        check(self.lib.gwbp_render_pixels(*self._args(), C.byref(view), ptr(colors), D, ptr(out), ptr(alphas),
+                                          self._stream()), "gwbp_render_pixels")
+        return out, alphas
+
+    def sh_colors(self, degree: int, means, coeffs, campos):
+        """[N,K,3] SH coefficients -> [N,3] view-dependent colours (+0.5, clamped at 0) on the device."""
+        means = _req(means, "means", (3,))
+        coeffs = _req(coeffs, "sh coefficients")
+        if coeffs.dim() != 3 or coeffs.shape[2] != 3 or coeffs.shape[0] != means.shape[0]:
+            raise GwbpError(f"SH coefficients must be [N,K,3], got {tuple(coeffs.shape)}")
+        out = torch.empty(means.shape[0], 3, device=self.device)
+        cp = (C.c_float * 3)(*[float(v) for v in campos])
+        check(self.lib.gwbp_sh_colors(C.c_int64(means.shape[0]), int(degree), coeffs.shape[1], ptr(means), ptr(coeffs),
+                                      cp, ptr(out), self._stream()), "gwbp_sh_colors")
+        return out
+
     def _check_acc(self, F, d, D):
         if F.dtype != torch.float32 or not F.is_cuda or not F.is_contiguous() or tuple(F.shape) != (self.n, D):
             raise GwbpError(f"F must be a contiguous float32 HIP tensor [{self.n},{D}]")

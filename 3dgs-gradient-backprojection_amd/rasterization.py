@@ -33,13 +33,13 @@ def get_engine(device, n: int, width: int, height: int) -> Engine:
     return eng
 
 
-def _run_front(eng: Engine, view, means, quats, scales, opacities, want_alphas, want_meta):
-    """project -> sort -> blend with auto-grow of the capacities (one host sync per call: this is the
+def _run_front(eng: Engine, view, means, quats, scales, opacities, want_alphas, want_meta, want_store=True):
+    """project -> sort (-> blend) with auto-grow of the capacities (one host sync per call: this is the
     API-compatible path; the fused driver in backproject.py amortises the check)."""
     while True:
         proj = eng.project(view, means, quats, scales, opacities, want_outputs=want_meta)
         bins = eng.bin_sort(view, want_outputs=want_meta)
-        alphas = eng.blend_weights(view, want_alphas=want_alphas)
+        alphas = eng.blend_weights(view, want_alphas=want_alphas) if want_store else None
         st = eng.stats()
         if not st["overflow"]:
             eng.generation += 1
@@ -53,8 +53,15 @@ class _Rasterize(torch.autograd.Function):
         dev = means.device
         eng = get_engine(dev, means.shape[0], width, height)
         view = eng.view(viewmat, K, width, height, **kw)
-        proj, bins, alphas, st = _run_front(eng, view, means, quats, scales, opacities, True, holder is not None)
-        out = eng.render(view, colors.detach())
+        D = colors.shape[1]
+        need_store = colors.requires_grad or D > 4  # the weight store is only needed for backward / the wide render
+        proj, bins, alphas, st = _run_front(eng, view, means, quats, scales, opacities, D > 4, holder is not None,
+                                            want_store=need_store)
+        if D <= 4:  # RGB / RGB+D / depth: pixel-parallel rasteriser straight from the sorted tile lists
+            out, alphas = eng.render_pixels(view, colors.detach())
+        else:
+            out = eng.render(view, colors.detach())
+        ctx.has_store = need_store
         if holder is not None:
             holder.update(proj=proj, bins=bins, stats=st)
         ctx.eng, ctx.view, ctx.gen = eng, view, eng.generation
@@ -70,7 +77,7 @@ class _Rasterize(torch.autograd.Function):
                                       "(backproject.py:67-72,129,147)")
         eng, view = ctx.eng, ctx.view
         means, quats, scales, opacities = ctx.saved_tensors
-        if eng.generation != ctx.gen or eng.n != means.shape[0]:
+        if eng.generation != ctx.gen or eng.n != means.shape[0] or not ctx.has_store:
             # the workspace was reused by another call since forward: rebuild this view's weight store
             eng = get_engine(means.device, means.shape[0], view.width, view.height)
             _run_front(eng, view, means, quats, scales, opacities, False, False)
@@ -190,9 +197,11 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         if sh_degree is not None:
             # colors is [N,K,3] (or [C,N,K,3]); view-dependent colour + 0.5, clamped at 0 (gsplat semantics)
             sh = colors if colors.dim() == 3 else colors[c]
-            campos = -(vm[:3, :3].T @ vm[:3, 3])
-            nb = (sh_degree + 1) ** 2
-            cols = torch.clamp_min(spherical_harmonics(sh_degree, means - campos, sh[:, :nb]) + 0.5, 0.0)
+            vm_h = vm.detach().cpu()
+            campos = (-(vm_h[:3, :3].T @ vm_h[:3, 3])).tolist()
+            if sh.requires_grad:
+                raise NotImplementedError("gradients w.r.t. SH coefficients are not on the reference's path")
+            cols = get_engine(means.device, N, width, height).sh_colors(sh_degree, means, sh, campos)
         else:
             cols = colors if colors.dim() == 2 else colors[c]
         holder = {} if (want_meta or "D" in render_mode) else None

@@ -104,6 +104,17 @@ int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
 int gwbp_render(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                 const float *colors, int32_t D, float *out, void *stream);
 
+/* Forward render for 1..4 channels (RGB, RGB+D, depth) straight from the sorted tile lists (needs gwbp_project +
+ * gwbp_bin_sort of the same view, not the weight store): the render the reference feeds to its 2-D feature network
+ * (backproject.py:89-100) and compares in utils.test_proper_pruning (utils.py:316-340).  alphas[H*W] optional. */
+int gwbp_render_pixels(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                       const float *colors, int32_t D, float *out, float *alphas, void *stream);
+
+/* gsplat spherical_harmonics + "+0.5, clamp at 0": coeffs[N,K,3] (K >= (degree+1)^2, degree <= 3), view directions
+ * means - campos_host[3]; out[N,3].  What rasterization(..., sh_degree=3) does before rasterising (backproject.py:99). */
+int gwbp_sh_colors(int64_t N, int32_t degree, int32_t K, const float *means, const float *coeffs,
+                   const float *campos_host, float *out, void *stream);
+
 /* ---- fused entry points --------------------------------------------------------------------------------- */
 
 /* project -> bin_sort -> blend_weights -> scatter for one view: the per-view body of

@@ -561,6 +561,42 @@ int orc_finalize(int64_t N, int D, int acc_double, const void *F, const void *d,
     return ORC_OK;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * 7. View-dependent colours: real SH basis up to degree 3 evaluated in double, + 0.5, clamp at 0
+ * (what gsplat.rasterization(..., sh_degree=3) does before rasterising; backproject.py:89-100).
+ * ---------------------------------------------------------------------------------------------- */
+int orc_sh_colors(int64_t N, int degree, int K, const float *means, const float *coeffs, const float *campos,
+                  float *out)
+{
+    if (degree < 0 || degree > 3 || K < (degree + 1) * (degree + 1))
+        return ORC_EINVAL;
+    for (int64_t i = 0; i < N; ++i) {
+        double x = (double)means[3 * i] - campos[0], y = (double)means[3 * i + 1] - campos[1],
+               z = (double)means[3 * i + 2] - campos[2];
+        const double n = sqrt(x * x + y * y + z * z);
+        x /= n, y /= n, z /= n;
+        double b[16];
+        const double xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        b[0] = 0.28209479177387814;
+        b[1] = -0.4886025119029199 * y, b[2] = 0.4886025119029199 * z, b[3] = -0.4886025119029199 * x;
+        b[4] = 1.0925484305920792 * xy, b[5] = -1.0925484305920792 * yz, b[6] = 0.31539156525252005 * (2 * zz - xx - yy);
+        b[7] = -1.0925484305920792 * xz, b[8] = 0.5462742152960396 * (xx - yy);
+        b[9] = -0.5900435899266435 * y * (3 * xx - yy), b[10] = 2.890611442640554 * xy * z;
+        b[11] = -0.4570457994644658 * y * (4 * zz - xx - yy), b[12] = 0.3731763325901154 * z * (2 * zz - 3 * xx - 3 * yy);
+        b[13] = -0.4570457994644658 * x * (4 * zz - xx - yy), b[14] = 1.445305721320277 * z * (xx - yy);
+        b[15] = -0.5900435899266435 * x * (xx - 3 * yy);
+        const int nb = (degree + 1) * (degree + 1);
+        for (int c = 0; c < 3; ++c) {
+            double v = 0.0;
+            for (int k = 0; k < nb; ++k)
+                v += b[k] * (double)coeffs[((size_t)i * K + k) * 3 + c];
+            v += 0.5;
+            out[3 * i + c] = (float)(v > 0.0 ? v : 0.0);
+        }
+    }
+    return ORC_OK;
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

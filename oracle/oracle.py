@@ -133,6 +133,15 @@ def render(proj, bins, opacities, colors, W: int, H: int, tile_size=16):
     return out, alphas
 
 
+def sh_colors(degree: int, means, coeffs, campos) -> np.ndarray:
+    means, coeffs, campos = _f32(means), _f32(coeffs), _f32(campos)
+    out = np.zeros((means.shape[0], 3), np.float32)
+    rc = lib().orc_sh_colors(C.c_int64(means.shape[0]), degree, coeffs.shape[1], _p(means), _p(coeffs), _p(campos), _p(out))
+    if rc:
+        raise RuntimeError(f"orc_sh_colors failed: {rc}")
+    return out
+
+
 def finalize(F: np.ndarray, d: np.ndarray) -> np.ndarray:
     out = np.zeros(F.shape, np.float32)
     lib().orc_finalize(C.c_int64(F.shape[0]), F.shape[1], int(F.dtype == np.float64), _p(F), _p(d), _p(out))

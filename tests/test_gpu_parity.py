@@ -261,3 +261,56 @@ def test_hip_path_reproduces_golden_vectors(dev):
     assert st["n_pairs"] == int(g["n_pairs"].sum())
     assert rel_row_err(F.cpu().numpy(), g["F"]) <= TOL and rel_row_err(d.cpu().numpy()[:, None], g["d"][:, None]) <= TOL
     assert np.abs(out.cpu().numpy() - g["out"]).max() <= TOL
+
+
+def test_sh_rgb_render_through_shim(orc, dev):
+    """backproject.py:89-100: rasterization(..., colors_all [N,16,3], sh_degree=3) under no_grad; plus RGB+D
+    (click_and_segment.py:251) and backgrounds.  SH colours and the pixel-parallel render vs the oracle."""
+    from gsbp_amd import rasterization
+    cfg, sc = scene_np("T1")
+    d, h = to_dev(sc, dev), npy(sc)
+    N = cfg.n_gaussians
+    g = torch.Generator().manual_seed(11)
+    sh = torch.randn(N, 16, 3, generator=g) * 0.3
+    v = 0
+    vm = h["vms"][v]
+    campos = -(vm[:3, :3].T @ vm[:3, 3])
+    with torch.no_grad():
+        out, alpha, meta = rasterization(d["means"], d["quats"], d["scales"], d["opac"], sh.to(dev), d["vms"][v][None],
+                                         d["K"][None], width=cfg.width, height=cfg.height, sh_degree=3)
+    cols_ref = orc.sh_colors(3, h["means"], sh.numpy(), campos)
+    eng = gsbp_amd.Engine(N, cfg.width, cfg.height, device=dev)
+    cols = eng.sh_colors(3, d["means"], sh.to(dev), campos.tolist()).cpu().numpy()
+    assert np.abs(cols - cols_ref).max() < 2e-6
+    ref_p = orc.project(h["means"], h["quats"], h["scales"], vm, h["K"], cfg.width, cfg.height)
+    ref_b = orc.bin_sort(ref_p, cfg.width, cfg.height)
+    ref, ralpha = orc.render(ref_p, ref_b, h["opac"], cols_ref, cfg.width, cfg.height)
+    assert out.shape == (1, cfg.height, cfg.width, 3) and alpha.shape == (1, cfg.height, cfg.width, 1)
+    assert np.abs(out[0].cpu().numpy() - ref).max() < 1e-5
+    assert np.array_equal(alpha[0, :, :, 0].cpu().numpy().view(np.uint32), ralpha.view(np.uint32))
+    # RGB+D with a background colour
+    bg = torch.tensor([[0.2, 0.4, 0.6, 0.0]], device=dev)
+    rgb = torch.rand(N, 3, generator=g)
+    with torch.no_grad():
+        outd, alphad, _ = rasterization(d["means"], d["quats"], d["scales"], d["opac"], rgb.to(dev), d["vms"][v][None],
+                                        d["K"][None], cfg.width, cfg.height, render_mode="RGB+D", backgrounds=bg,
+                                        want_meta=False)
+    z = (h["means"] @ vm[:3, :3].T + vm[:3, 3])[:, 2:3]
+    refd, _ = orc.render(ref_p, ref_b, h["opac"], np.concatenate([rgb.numpy(), z], 1).astype(np.float32), cfg.width,
+                         cfg.height)
+    refd = refd + (1.0 - ralpha[..., None]) * bg.cpu().numpy()[0]
+    assert np.abs(outd[0].cpu().numpy() - refd).max() < 2e-5
+
+
+def test_prune_mask_equals_reference_rule(orc, dev):
+    """utils.prune_by_gradients (utils.py:222-271): keep Gaussians with accumulated |colour grad| > 0 == d > 0."""
+    cfg, sc = scene_np("T1")
+    d, h = to_dev(sc, dev), npy(sc)
+    feats_all = [syn.make_feature_map(cfg, v, dim=4) for v in range(cfg.n_views)]
+    _, _, dd, _ = gsbp_amd.create_feature_field(d["means"], d["quats"], d["scales"], d["opac"], d["vms"], d["K"],
+                                                cfg.width, cfg.height, lambda v: feats_all[v].to(dev), 4,
+                                                return_partials=True)
+    _, _, dr, _ = orc.backproject_oracle(h["means"], h["quats"], h["scales"], h["opac"], h["vms"], h["K"], cfg.width,
+                                         cfg.height, lambda v: feats_all[v].numpy(), 4)
+    mask = gsbp_amd.prune_mask(dd).cpu().numpy()
+    assert np.array_equal(mask, dr > 0) and 0 < mask.sum() < cfg.n_gaussians
