@@ -54,9 +54,12 @@ struct EV { // entries 64j .. 64j+63 of a record, one per lane
     float w;
     u32 pix;
 };
+// "+v" (tied operand): the load lands in the SAME physical registers that currently hold dst.  With a plain "=v"
+// output hipcc may rename the destination per iteration and reconcile the names with a v_mov on a loop back-edge --
+// a copy of registers whose data has not arrived yet (observed in a single-body variant of the record loop).
 __device__ __forceinline__ void issue_e(EV &dst, const WPair *p)
 {
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(*reinterpret_cast<float2 *>(&dst)) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(*reinterpret_cast<float2 *>(&dst)) : "v"(p) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_e(EV (&e)[2])
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
         off = (s >= R.base[3]) ? R.woff[3] + (s - R.base[3]) : off;
         return off;
     };
-    auto prefetch = [&](const Rec &R, EV (&e)[2]) { // exactly 2 VMEM loads (slots 0..127, clamped to the last one)
+    auto prefetch = [&](const Rec &R, EV (&e)[2]) __attribute__((always_inline)) { // exactly 2 VMEM loads (slots 0..127, clamped to the last one)
         const u32 last = R.T ? R.T - 1 : 0u;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
 
     float2 acc;
     // n in 1..64 entries held by lanes 0..n-1 of ev (lanes >= n: w = 0, pix = any valid pixel)
-    auto run_vec = [&](const EV &ev, u32 n) {
+    auto run_vec = [&](const EV &ev, u32 n) __attribute__((always_inline)) {
         float2 fa[8], fb[8];
 #define GWBP_ISSUE8(B, f)                                                                                             \
     _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                     \
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
 #undef GWBP_ISSUE8
 #undef GWBP_FMA8
     };
-    auto process = [&](const Rec &R, const EV (&e)[2]) { // exactly 2 (+1 if want_d) VMEM atomics, always
+    auto process = [&](const Rec &R, const EV (&e)[2]) __attribute__((always_inline)) { // exactly 2 (+1 if want_d) VMEM atomics, always
         acc = make_float2(0.f, 0.f);
         float wacc = 0.f;
         if (!(dbg & 2)) {
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
         }
     };
 
-    EV eA[2], eB[2];
+    EV eA[2] = {{0.f, 0u}, {0.f, 0u}}, eB[2] = {{0.f, 0u}, {0.f, 0u}};
     u32 h = claim();
     if (h >= nh)
         return;
