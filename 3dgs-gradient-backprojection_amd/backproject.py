@@ -81,13 +81,18 @@ class ViewPipeline:
         self.pending[self.i_front] = view
         self.i_front += 1
 
-    def scatter(self, feats, F, d, scale_f=1.0, scale_d=1.0):
+    def scatter(self, feats, F, d, scale_f=1.0, scale_d=1.0, t0=None, t1=None):
+        """t0/t1: optional timing events recorded right around the scatter launch (after the cross-stream wait)."""
         i = self.i_scatter
         b = i % 2
         main = torch.cuda.current_stream(self.dev)
         main.wait_event(self.ev_front[b])
         e = self.eng[b]
+        if t0 is not None:
+            t0.record(main)
         e.scatter(self.pending.pop(i), feats, F, d, scale_f, scale_d)
+        if t1 is not None:
+            t1.record(main)
         e.accumulate_stats(self.accum)
         self.ev_done[b].record(main)
         self.i_scatter += 1

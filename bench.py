@@ -118,11 +118,8 @@ def main():
             if 0 <= k < args.steps:
                 ev[k][3].record()
             return
-        if 0 <= k < args.steps:
-            ev[k][2].record()
-        pipe.scatter(feats, F, d)
-        if 0 <= k < args.steps:
-            ev[k][3].record()
+        timed = 0 <= k < args.steps
+        pipe.scatter(feats, F, d, t0=ev[k][2] if timed else None, t1=ev[k][3] if timed else None)
 
     front(0)
     for i in range(args.warmup):

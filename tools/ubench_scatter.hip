@@ -23,6 +23,9 @@ __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ w
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 32768; i += 1024)
         lds[i] = (float)(i & 255) * 1e-3f;
+    for (int i = threadIdx.x; i < 2048; i += 1024) { // per-wave entry tables for modes 6/7
+        lds[32768 + i] = (i & 1) ? __int_as_float((i * 37) & 255) : 0.001f * (i % 97);
+    }
     __syncthreads();
     float wv = wsrc[(wave * 64 + lane) & 1023];
     int pv = psrc[(wave * 64 + lane) & 1023] & 255;
@@ -86,6 +89,43 @@ __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ w
                     acc.x = __builtin_fmaf(w, f[j].x, acc.x);
                     acc.y = __builtin_fmaf(w, f[j].y, acc.y);
                 }
+            } else if (MODE == 6 || MODE == 7) {
+                // entries {w, pix} of this wave live in LDS (written once per 64 entries); broadcast reads bring them
+                // into VGPRs as wave-uniform values: no v_readlane at all
+                const char *ent = slab + 131072 + wave * 512; // 64 entries x 8 B per wave (extra 8 KB of LDS)
+                if (MODE == 6) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float2 e = *(const float2 *)(ent + 8 * (8 * b + j));
+                        const int p = __float_as_int(e.y) & 255;
+                        f[j] = *(const float2 *)(slab + ((p << 9) + lane_base));
+                        acc2.x += e.x;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float2 e = *(const float2 *)(ent + 8 * (8 * b + j));
+                        acc.x = __builtin_fmaf(e.x, f[j].x, acc.x);
+                        acc.y = __builtin_fmaf(e.x, f[j].y, acc.y);
+                    }
+                } else {
+                    float4 e4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        e4[j] = *(const float4 *)(ent + 16 * (4 * b + j));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int p0 = __float_as_int(e4[j].y) & 255, p1 = __float_as_int(e4[j].w) & 255;
+                        f[2 * j] = *(const float2 *)(slab + ((p0 << 9) + lane_base));
+                        f[2 * j + 1] = *(const float2 *)(slab + ((p1 << 9) + lane_base));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc.x = __builtin_fmaf(e4[j].x, f[2 * j].x, acc.x);
+                        acc.y = __builtin_fmaf(e4[j].x, f[2 * j].y, acc.y);
+                        acc.x = __builtin_fmaf(e4[j].z, f[2 * j + 1].x, acc.x);
+                        acc.y = __builtin_fmaf(e4[j].z, f[2 * j + 1].y, acc.y);
+                    }
+                }
             } else if (MODE == 5) {
                 float4 g[8];
 #pragma unroll
@@ -111,14 +151,14 @@ __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ w
 template <int MODE>
 void run(const char *name, int iters, const float *w, const int *p, float *out)
 {
-    CHECK(hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CHECK(hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 8192));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    k<MODE><<<256, 1024, 131072>>>(iters, w, p, out);
+    k<MODE><<<256, 1024, 131072 + 8192>>>(iters, w, p, out);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    k<MODE><<<256, 1024, 131072>>>(iters, w, p, out);
+    k<MODE><<<256, 1024, 131072 + 8192>>>(iters, w, p, out);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms;
@@ -147,5 +187,7 @@ int main()
     run<3>("3 b64 + pkfma only", iters, w, p, out);
     run<4>("4 bpermute x2 + add + b64 + pkfma", iters, w, p, out);
     run<5>("5 readlane x2 + add + b128 + 2pkfma", iters, w, p, out);
+    run<6>("6 LDS bcast b64/pair + add+b64+pkfma", iters, w, p, out);
+    run<7>("7 LDS bcast b128/2pairs + ...", iters, w, p, out);
     return 0;
 }
