@@ -6,7 +6,7 @@
 // (Gaussian, pixel) pair:
 //
 //   workgroup = one 16x16 tile, 256 threads; wave q owns tile rows 4q..4q+3, lane l -> pixel q*64 + l
-//   per batch of <= 256 list entries: Gaussian records staged in LDS (2 x 16-B broadcast reads per evaluation)
+//   per batch of <= kBatch list entries: Gaussian records staged in LDS (2 x 16-B broadcast reads per evaluation)
 //   per (Gaussian, wave): mask = ballot(contributes); the popc(mask) {w, pixel} entries are written compacted
 //     (lane rank = mbcnt, 8-B stores) into a per-wave stream carved from a global pool in pages of kPage entries,
 //     each list zero-padded to a multiple of 8 entries (= one s_load_dwordx16 in the scatter kernel)
@@ -20,16 +20,20 @@
 
 namespace gwbp {
 
+constexpr int kBatch = 128;
+
 __global__ __launch_bounds__(256) void k_blend(ViewDev V, const u32 *__restrict__ tile_offsets,
                                                const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
                                                Counters *__restrict__ ctr, Header *__restrict__ headers,
                                                u32 *__restrict__ hdr_count, WPair *__restrict__ wpool,
                                                u32 pair_cap, u32 *__restrict__ shards, float *__restrict__ alphas, int dbg)
 {
-    __shared__ float4 s_a[256]; // mx, my, opac, gid bits
-    __shared__ float4 s_b[256]; // ca, cb, cc, -
-    __shared__ u64 s_mask[256][4];
-    __shared__ u32 s_woff[256][4];
+    // kBatch list entries are staged per round; 128 keeps the workgroup at 10 KB of LDS so that two of them fit beside
+    // the 139 KB scatter workgroup when the two kernels overlap (ViewPipeline)
+    __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
+    __shared__ float4 s_b[kBatch]; // ca, cb, cc, strip mask
+    __shared__ u64 s_mask[kBatch][4];
+    __shared__ u32 s_woff[kBatch][4];
     __shared__ u32 s_wsum[4];
     __shared__ u32 s_hdrn;
 
@@ -56,11 +60,11 @@ __global__ __launch_bounds__(256) void k_blend(ViewDev V, const u32 *__restrict_
     if (threadIdx.x == 0)
         s_hdrn = 0;
 
-    for (u32 batch = beg; batch < end; batch += 256) {
+    for (u32 batch = beg; batch < end; batch += kBatch) {
         // barrier + early exit when every pixel of the tile has terminated (gsplat: __syncthreads_count(done))
         if (__syncthreads_count(done) == 256)
             break;
-        const u32 bn = min(256u, end - batch);
+        const u32 bn = min((u32)kBatch, end - batch);
         if (threadIdx.x < bn) {
             const u32 gid = vals[batch + threadIdx.x];
             const float4 *gp = reinterpret_cast<const float4 *>(g2d + gid);
@@ -271,7 +275,10 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
 {
     const int n_tiles = V.tile_w * V.tile_h;
     const int fin = sort_passes(n_tiles) & 1;
-    hipLaunchKernelGGL(k_blend, dim3(n_tiles), dim3(256), 0, s, V, W.tile_offsets, W.vals[fin], W.g2d, W.counters,
+    static int extra_lds = -1; // experiment knob: pad the workgroup's LDS footprint to cap co-residency
+    if (extra_lds < 0)
+        extra_lds = getenv("GWBP_BLEND_LDS") ? atoi(getenv("GWBP_BLEND_LDS")) : 0;
+    hipLaunchKernelGGL(k_blend, dim3(n_tiles), dim3(256), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d, W.counters,
                        W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, alphas,
                        getenv("GWBP_ABLATE_BLEND") ? atoi(getenv("GWBP_ABLATE_BLEND")) : 0);
     hipLaunchKernelGGL(k_pool_stats, dim3(1), dim3(1), 0, s, W.shards, W.counters);
