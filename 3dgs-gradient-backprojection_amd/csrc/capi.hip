@@ -218,7 +218,7 @@ int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
         return rc;
     if ((rc = check_feats(feats, fs_y, fs_x, fs_c, D)))
         return rc;
-    if (!F)
+    if (!F && L.n > 0)
         return set_error(GWBP_EINVAL, "null F");
     return launch_scatter(L, W, V, feats, fs_y, fs_x, fs_c, D, scale_f, scale_d, F, d,
                           static_cast<hipStream_t>(stream));
@@ -280,7 +280,7 @@ int gwbp_backproject_view(const gwbp_caps *caps, void *workspace, size_t workspa
         return rc;
     if ((rc = check_feats(feats, fs_y, fs_x, fs_c, D)))
         return rc;
-    if (!F)
+    if (!F && L.n > 0)
         return set_error(GWBP_EINVAL, "null F");
     if (L.n > 0 && (!means || !quats || !scales || !opacities))
         return set_error(GWBP_EINVAL, "null Gaussian parameter pointer");

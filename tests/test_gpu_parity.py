@@ -314,3 +314,71 @@ def test_prune_mask_equals_reference_rule(orc, dev):
                                          cfg.height, lambda v: feats_all[v].numpy(), 4)
     mask = gsbp_amd.prune_mask(dd).cpu().numpy()
     assert np.array_equal(mask, dr > 0) and 0 < mask.sum() < cfg.n_gaussians
+
+
+def test_edge_cases_zero_gaussians_tiny_image_and_huge_splats(orc, dev):
+    """N = 0; an image smaller than one tile; Gaussians covering the whole image (records with > 128 entries per
+    tile exercise the rare multi-vector path); non-multiple-of-16 sizes."""
+    # N = 0
+    eng0 = gsbp_amd.Engine(0, 40, 24, device=dev)
+    z3, z4, z1 = torch.zeros(0, 3, device=dev), torch.zeros(0, 4, device=dev), torch.zeros(0, device=dev)
+    F0, d0 = torch.zeros(0, 8, device=dev), torch.zeros(0, device=dev)
+    view = eng0.view(torch.eye(4), torch.tensor([[50.0, 0, 20], [0, 50.0, 12], [0, 0, 1]]), 40, 24)
+    eng0.backproject_view(view, z3, z4, z3, z1, torch.rand(24, 40, 8, device=dev), F0, d0)
+    assert eng0.stats()["n_pairs"] == 0
+    # 13 x 9 image (one partial tile), 3 huge + 20 small Gaussians, D = 5 (odd channel count)
+    W, H, D = 13, 9, 5
+    g = torch.Generator().manual_seed(3)
+    n = 23
+    means = torch.cat([torch.tensor([[0.0, 0.0, 2.0]] * 3), torch.rand(20, 3, generator=g) * torch.tensor([1.0, 0.6, 1.0])
+                       + torch.tensor([-0.5, -0.3, 1.5])])
+    scales = torch.cat([torch.full((3, 3), 2.0), torch.full((20, 3), 0.05)])
+    quats = torch.randn(n, 4, generator=g)
+    opac = torch.cat([torch.tensor([0.02, 0.3, 0.9]), torch.rand(20, generator=g)])
+    K = torch.tensor([[15.0, 0, W / 2], [0, 15.0, H / 2], [0, 0, 1]])
+    vm = torch.eye(4)
+    feats = torch.randn(H, W, D, generator=g)
+    eng = gsbp_amd.Engine(n, W, H, device=dev)
+    F = torch.zeros(n, D, device=dev)
+    dd = torch.zeros(n, device=dev)
+    eng.backproject_view(eng.view(vm, K, W, H), means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev),
+                         feats.to(dev), F, dd)
+    Fr, dr = np.zeros((n, D)), np.zeros(n)
+    info = orc.backproject_view(means.numpy(), quats.numpy(), scales.numpy(), opac.numpy(), vm.numpy(), K.numpy(), W, H,
+                                feats.numpy(), Fr, dr)
+    assert eng.stats()["n_pairs"] == info["n_pairs"] > 0
+    assert rel_row_err(F.cpu().numpy(), Fr) <= TOL and rel_row_err(dd.cpu().numpy()[:, None], dr[:, None]) <= TOL
+    # whole-screen splats at D = 128 through the fast path: every tile record has up to 256 entries
+    W, H, D = 96, 64, 128
+    K = torch.tensor([[80.0, 0, W / 2], [0, 80.0, H / 2], [0, 0, 1]])
+    n = 6
+    means = torch.tensor([[0.0, 0.0, 2.0 + 0.1 * i] for i in range(n)])
+    scales = torch.full((n, 3), 3.0)
+    quats = torch.randn(n, 4, generator=g)
+    opac = torch.full((n,), 0.05)
+    feats = torch.randn(H, W, D, generator=g)
+    eng = gsbp_amd.Engine(n, W, H, device=dev)
+    F = torch.zeros(n, D, device=dev)
+    dd = torch.zeros(n, device=dev)
+    eng.backproject_view(eng.view(vm, K, W, H), means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev),
+                         feats.to(dev), F, dd)
+    Fr, dr = np.zeros((n, D)), np.zeros(n)
+    info = orc.backproject_view(means.numpy(), quats.numpy(), scales.numpy(), opac.numpy(), vm.numpy(), K.numpy(), W, H,
+                                feats.numpy(), Fr, dr)
+    assert eng.stats()["n_pairs"] == info["n_pairs"] == n * W * H  # every Gaussian reaches every pixel
+    assert rel_row_err(F.cpu().numpy(), Fr) <= TOL and rel_row_err(dd.cpu().numpy()[:, None], dr[:, None]) <= TOL
+
+
+def test_pipelined_driver_equals_serial_driver(dev):
+    cfg, sc = scene_np("T1", n_views=5)
+    d = to_dev(sc, dev)
+    vms = syn.make_cameras(cfg, n_views=5).to(dev)
+    feats_all = [syn.make_feature_map(cfg, v).to(dev) for v in range(5)]
+    res = []
+    for pipeline in (True, False):
+        out, F, dd, st = gsbp_amd.create_feature_field(d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"],
+                                                        cfg.width, cfg.height, lambda v: feats_all[v], cfg.feat_dim,
+                                                        pipeline=pipeline, return_partials=True)
+        res.append((F.cpu().numpy(), dd.cpu().numpy(), st["n_pairs"]))
+    assert res[0][2] == res[1][2]
+    assert rel_row_err(res[0][0], res[1][0]) <= 1e-5 and np.abs(res[0][1] - res[1][1]).max() <= 1e-4 * res[1][1].max()
