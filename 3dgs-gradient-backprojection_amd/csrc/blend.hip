@@ -5,45 +5,40 @@
 // channel_chunk = 32); here it runs ONCE and its only product is w = alpha * T for every contributing
 // (Gaussian, pixel) pair:
 //
-//   workgroup = one 16x16 tile, 256 threads; wave q owns tile rows 4q..4q+3, lane l -> pixel q*64 + l
-//   per batch of <= kBatch list entries: Gaussian records staged in LDS (2 x 16-B broadcast reads per evaluation)
-//   per (Gaussian, wave): mask = ballot(contributes); the popc(mask) {w, pixel} entries are written compacted
-//     (lane rank = mbcnt, 8-B stores) into a per-wave stream carved from a global pool in pages of kPage entries,
-//     each list zero-padded to a multiple of 8 entries (= one s_load_dwordx16 in the scatter kernel)
-//   per (Gaussian, tile) with any contribution: one 64-B Header {gid, 4 x woff, 4 x mask}, compacted in list order
+//   workgroup = ONE WAVE = one 16x16 tile; lane l owns the four pixels (l % 16, 4q + l / 16), q = 0..3 ("quarters":
+//     tile rows 4q..4q+3), i.e. pixel index q*64 + l.  Four independent T chains per lane give the latency-bound
+//     loop 4-way instruction-level parallelism; a single wave needs no workgroup barrier and no header compaction.
+//   per batch of 64 list entries: projected Gaussians staged in LDS (2 x 16-B broadcast reads per entry) together
+//     with a conservative 4-bit strip mask (which quarters the Gaussian can reach at all)
+//   per contributing (Gaussian, tile) RECORD: mask[q] = ballot(contributes in quarter q); the entries {w, pixel} of
+//     the four quarters are written back to back (ascending pixel order, lane rank = mbcnt, 8-B stores) into the
+//     wave's stream carved from a sharded global pool in pages of kPage entries, zero-padded to a multiple of 8
+//     per record, followed by one 64-B Header {gid, woff[q], counts, mask[q]} in list order.
 //
-// Store size: 8 B per pair (+ padding) + 64 B per header (C2: ~0.8 GB + ~116 MB per view), written once, then read by the
-// scatter kernel once per 128-channel chunk through L2.
+// Store size: 8 B per pair (+ padding) + 64 B per header (C2: ~0.75 GB + ~115 MB per view), written once, then read
+// by the scatter kernel once per 128-channel chunk through L2.
 #include <stdlib.h>
 
 #include "gwbp_dev.h"
 
 namespace gwbp {
 
-constexpr int kBatch = 128;
+constexpr int kBatch = 64;
 
-__global__ __launch_bounds__(256) void k_blend(ViewDev V, const u32 *__restrict__ tile_offsets,
-                                               const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
-                                               Counters *__restrict__ ctr, Header *__restrict__ headers,
-                                               u32 *__restrict__ hdr_count, WPair *__restrict__ wpool,
-                                               u32 pair_cap, u32 *__restrict__ shards, float *__restrict__ alphas, int dbg)
+__global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__ tile_offsets,
+                                              const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
+                                              Counters *__restrict__ ctr, Header *__restrict__ headers,
+                                              u32 *__restrict__ hdr_count, WPair *__restrict__ wpool, u32 pair_cap,
+                                              u32 *__restrict__ shards, float *__restrict__ alphas, int dbg)
 {
-    // kBatch list entries are staged per round; 128 keeps the workgroup at 10 KB of LDS so that two of them fit beside
-    // the 139 KB scatter workgroup when the two kernels overlap (ViewPipeline)
     __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
     __shared__ float4 s_b[kBatch]; // ca, cb, cc, strip mask
-    __shared__ u64 s_mask[kBatch][4];
-    __shared__ u32 s_woff[kBatch][4];
-    __shared__ u32 s_wsum[4];
-    __shared__ u32 s_hdrn;
 
     const int tile = blockIdx.x;
     const int tx = tile % V.tile_w, ty = tile / V.tile_w;
-    const int lane = threadIdx.x & 63;
-    const int wave = (int)uniform(threadIdx.x >> 6); // scalar: everything derived from it stays wave-uniform
-    const int ix = tx * kTile + (lane & 15), iy = ty * kTile + wave * 4 + (lane >> 4);
-    const bool inside = ix < V.W && iy < V.H;
-    const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
+    const int lane = threadIdx.x;
+    const int ix = tx * kTile + (lane & 15), iy0 = ty * kTile + (lane >> 4);
+    const float px = (float)ix + 0.5f;
     const u32 beg = tile_offsets[tile], end = tile_offsets[tile + 1];
 
     // The weight pool is carved into kShards regions with their own head words: a single head saturates at
@@ -53,20 +48,29 @@ __global__ __launch_bounds__(256) void k_blend(ViewDev V, const u32 *__restrict_
     const u32 shard_base = shard * shard_cap;
     u32 *shard_head = shards + shard * 16;
 
-    float T = 1.0f;
-    bool done = !inside;
-    u32 page_pos = 0, page_left = 0, npairs = 0; // wave-uniform
-    bool dead = false;                           // wave-uniform: pool exhausted
-    if (threadIdx.x == 0)
-        s_hdrn = 0;
+    float T[4], py[4];
+    bool done[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int iy = iy0 + 4 * q;
+        py[q] = (float)iy + 0.5f;
+        T[q] = 1.0f;
+        done[q] = !(ix < V.W && iy < V.H);
+    }
+    u32 page_pos = 0, page_left = 0, npairs = 0, hdr_n = 0; // wave-uniform
+    bool dead = false;                                     // wave-uniform: pool exhausted
 
     for (u32 batch = beg; batch < end; batch += kBatch) {
-        // barrier + early exit when every pixel of the tile has terminated (gsplat: __syncthreads_count(done))
-        if (__syncthreads_count(done) == 256)
+        // quarters that still have a live pixel; stop when the whole tile has terminated (gsplat: all threads done)
+        u32 alive = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            alive |= (__ballot(!done[q]) != 0ull ? 1u : 0u) << q;
+        if (alive == 0)
             break;
         const u32 bn = min((u32)kBatch, end - batch);
-        if (threadIdx.x < bn) {
-            const u32 gid = vals[batch + threadIdx.x];
+        if ((u32)lane < bn) {
+            const u32 gid = vals[batch + lane];
             const float4 *gp = reinterpret_cast<const float4 *>(g2d + gid);
             const float4 a = gp[0], b = gp[1];
             // Conservative strip mask: bit q set <=> the Gaussian MAY reach alpha >= 1/255 somewhere in tile rows
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void k_blend(ViewDev V, const u32 *__restrict_
                 const float ey = 1.05f * __builtin_sqrtf(2.0f * L * b.x * idet) + 1.0f;
                 const float x0 = (float)(tx * kTile) + 0.5f, y0 = (float)(ty * kTile) + 0.5f;
                 const bool xhit = !(a.x + ex < x0 || a.x - ex > x0 + 15.0f);
-                if (xhit || !(ex == ex)) {
+                if (xhit) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float ya = y0 + 4.0f * q;
@@ -93,22 +97,60 @@ __global__ __launch_bounds__(256) void k_blend(ViewDev V, const u32 *__restrict_
                 if (!(ex == ex) || !(ey == ey))
                     smask = 0xFu; // degenerate conic: never reject
             }
-            s_a[threadIdx.x] = make_float4(a.x, a.y, a.z, __int_as_float((int)gid));
-            s_b[threadIdx.x] = make_float4(b.x, b.y, b.z, __int_as_float((int)smask));
-            s_mask[threadIdx.x][0] = 0ull, s_mask[threadIdx.x][1] = 0ull;
-            s_mask[threadIdx.x][2] = 0ull, s_mask[threadIdx.x][3] = 0ull;
+            s_a[lane] = make_float4(a.x, a.y, a.z, __int_as_float((int)gid));
+            s_b[lane] = make_float4(b.x, b.y, b.z, __int_as_float((int)smask));
         }
-        __syncthreads();
+        // single wave: LDS operations of one wave complete in program order, no barrier needed
 
-        // Per-lane control flow is written branch-free (selects); the only branches in the loop are wave-uniform.
-        // Two list entries are evaluated per iteration: their sigma / exp / alpha chains are independent (only the
-        // T update is sequential), which doubles the instruction-level parallelism of this latency-bound loop.
-        auto emit = [&](u32 j, bool valid, float w) {
-            const u64 mask = __ballot(valid);
-            if (mask == 0ull)
-                return;
-            const u32 cnt = (u32)__popcll(mask);
-            const u32 padded = (cnt + (kListPad - 1)) & ~(u32)(kListPad - 1);
+        for (u32 j = 0; j < bn && !(dbg & 2); ++j) {
+            const float4 b = s_b[j];
+            const u32 sm = uniform((u32)__float_as_int(b.w)) & alive;
+            if (sm == 0)
+                continue; // this Gaussian cannot reach any live quarter of the tile
+            const float4 a = s_a[j];
+            const float dx = a.x - px;
+            const float adx = b.x * dx, bdx = b.y * dx; // shared by the four quarters (same column)
+            u64 m[4];
+            float w[4];
+            bool valid[4];
+            // Per-lane control flow is branch-free (selects); the only branches are wave-uniform.
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                m[q] = 0ull, w[q] = 0.f, valid[q] = false;
+                if ((sm >> q) & 1u) {
+                    const float dy = a.y - py[q];
+                    const float sigma = __builtin_fmaf(bdx, dy, 0.5f * __builtin_fmaf(adx, dx, (b.z * dy) * dy));
+                    const float alpha = __builtin_fminf(kAlphaMax, a.z * exp_neg(-__builtin_fmaxf(sigma, 0.f)));
+                    const bool ok = !done[q] && (sigma >= 0.f) && (alpha >= kAlphaMin);
+                    const float next_T = T[q] * (1.0f - alpha);
+                    const bool term = ok && (next_T <= kTMin); // the terminating Gaussian is NOT counted
+                    valid[q] = ok && !term;
+                    w[q] = alpha * T[q];
+                    T[q] = valid[q] ? next_T : T[q];
+                    done[q] = done[q] || term;
+                    m[q] = __ballot(valid[q]);
+                }
+            }
+            if ((m[0] | m[1] | m[2] | m[3]) == 0ull) {
+                // a quarter may have died without contributing: refresh the live set lazily
+                if ((j & 7u) == 7u) {
+                    alive = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        alive |= (__ballot(!done[q]) != 0ull ? 1u : 0u) << q;
+                    if (alive == 0)
+                        break;
+                }
+                continue;
+            }
+            u32 cnt[4], base[4], total = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cnt[q] = (u32)__popcll(m[q]);
+                base[q] = total;
+                total += cnt[q];
+            }
+            const u32 padded = (total + (kListPad - 1)) & ~(u32)(kListPad - 1);
             if (padded > page_left) {
                 u32 old = 0;
                 if (lane == 0)
@@ -123,106 +165,50 @@ __global__ __launch_bounds__(256) void k_blend(ViewDev V, const u32 *__restrict_
                 }
             }
             if (!dead && !(dbg & 1)) {
-                if (valid) {
-                    WPair e;
-                    e.w = w, e.pix = (u32)(wave * 64 + lane);
-                    wpool[page_pos + mbcnt(mask)] = e;
-                }
-                if ((u32)lane < padded - cnt) { // {0, 0} tail so the scatter loop needs no remainder handling
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (valid[q]) {
+                        WPair e;
+                        e.w = w[q], e.pix = (u32)(q * 64 + lane);
+                        wpool[page_pos + base[q] + mbcnt(m[q])] = e;
+                    }
+                if ((u32)lane < padded - total) { // {0, 0} tail: the scatter loop needs no remainder handling
                     WPair z;
                     z.w = 0.f, z.pix = 0u;
-                    wpool[page_pos + cnt + lane] = z;
+                    wpool[page_pos + total + lane] = z;
                 }
                 if (lane == 0) {
-                    s_mask[j][wave] = mask;
-                    s_woff[j][wave] = page_pos;
+                    Header h;
+                    h.gid = (u32)__float_as_int(a.w);
+                    h.woff[0] = page_pos, h.woff[1] = page_pos + base[1];
+                    h.woff[2] = page_pos + base[2], h.woff[3] = page_pos + base[3];
+                    h.counts = cnt[0] | (cnt[1] << 8) | (cnt[2] << 16) | (cnt[3] << 24);
+                    h.pad[0] = h.pad[1] = 0;
+                    h.mask[0] = m[0], h.mask[1] = m[1], h.mask[2] = m[2], h.mask[3] = m[3];
+                    headers[beg + hdr_n] = h;
                 }
+                ++hdr_n;
             }
             page_pos += padded;
             page_left -= padded;
-            npairs += cnt;
-        };
-        auto alpha_of = [&](const float4 &a, const float4 &b, float &sigma) -> float {
-            const float dx = a.x - px, dy = a.y - py;
-            sigma = __builtin_fmaf(b.y * dx, dy, 0.5f * __builtin_fmaf(b.x * dx, dx, (b.z * dy) * dy));
-            if (dbg & 8)
-                return __builtin_fminf(kAlphaMax, a.z * (1.0f / (1.0f + sigma)));
-            return __builtin_fminf(kAlphaMax, a.z * exp_neg(-__builtin_fmaxf(sigma, 0.f)));
-        };
-        for (u32 j = 0; j < bn && !(dbg & 2); j += 2) {
-            if (__ballot(!done) == 0ull)
-                break; // every pixel of this wave's strip has terminated
-            const u32 j1 = min(j + 1, bn - 1);
-            const float4 b0 = s_b[j], b1 = s_b[j1];
-            const float4 a0 = s_a[j], a1 = s_a[j1];
-            const bool hit0 = (uniform((u32)__float_as_int(b0.w)) >> wave) & 1u;
-            const bool hit1 = ((uniform((u32)__float_as_int(b1.w)) >> wave) & 1u) && (j + 1 < bn);
-            if (!hit0 && !hit1 && !(dbg & 16))
-                continue; // neither Gaussian can reach this wave's strip
-            float sg0, sg1;
-            const float al0 = alpha_of(a0, b0, sg0), al1 = alpha_of(a1, b1, sg1);
-            // sequential part (front to back): entry j, then entry j+1
-            const bool ok0 = hit0 && !done && (sg0 >= 0.f) && (al0 >= kAlphaMin);
-            const float nT0 = T * (1.0f - al0);
-            const bool term0 = ok0 && (nT0 <= kTMin); // the terminating Gaussian is NOT counted
-            const bool v0 = ok0 && !term0;
-            const float w0 = al0 * T;
-            T = v0 ? nT0 : T;
-            done = done || term0;
-            const bool ok1 = hit1 && !done && (sg1 >= 0.f) && (al1 >= kAlphaMin);
-            const float nT1 = T * (1.0f - al1);
-            const bool term1 = ok1 && (nT1 <= kTMin);
-            const bool v1 = ok1 && !term1;
-            const float w1 = al1 * T;
-            T = v1 ? nT1 : T;
-            done = done || term1;
-            if (!(dbg & 4)) {
-                emit(j, v0, w0);
-                emit(j1, v1, w1);
-            }
+            npairs += total;
         }
-        __syncthreads();
-
-        // compact this batch's non-empty (Gaussian, tile) records into the tile's header run, in list order
-        bool has = false;
-        u64 m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-        if (threadIdx.x < bn) {
-            m0 = s_mask[threadIdx.x][0], m1 = s_mask[threadIdx.x][1];
-            m2 = s_mask[threadIdx.x][2], m3 = s_mask[threadIdx.x][3];
-            has = (m0 | m1 | m2 | m3) != 0ull;
-        }
-        const u64 hb = __ballot(has);
-        if (lane == 0)
-            s_wsum[wave] = (u32)__popcll(hb);
-        __syncthreads();
-        u32 off = s_hdrn + mbcnt(hb);
-        for (int w = 0; w < wave; ++w)
-            off += s_wsum[w];
-        if (has) {
-            Header h;
-            h.gid = (u32)__float_as_int(s_a[threadIdx.x].w);
-            h.woff[0] = s_woff[threadIdx.x][0], h.woff[1] = s_woff[threadIdx.x][1];
-            h.woff[2] = s_woff[threadIdx.x][2], h.woff[3] = s_woff[threadIdx.x][3];
-            h.counts = (u32)__popcll(m0) | ((u32)__popcll(m1) << 8) | ((u32)__popcll(m2) << 16) |
-                       ((u32)__popcll(m3) << 24);
-            h.pad[0] = h.pad[1] = 0;
-            h.mask[0] = m0, h.mask[1] = m1, h.mask[2] = m2, h.mask[3] = m3;
-            headers[beg + off] = h;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0)
-            s_hdrn += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        hdr_count[tile] = s_hdrn;
-        if (s_hdrn)
-            atomicAdd(&ctr->n_headers, s_hdrn);
+    if (lane == 0) {
+        hdr_count[tile] = hdr_n;
+        if (hdr_n)
+            atomicAdd(&ctr->n_headers, hdr_n);
+        if (npairs)
+            atomicAdd(&ctr->n_pairs, (u64)npairs);
     }
-    if (lane == 0 && npairs)
-        atomicAdd(&ctr->n_pairs, (u64)npairs);
-    if (alphas && inside)
-        alphas[(size_t)iy * V.W + ix] = 1.0f - T;
+    if (alphas) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int iy = iy0 + 4 * q;
+            if (ix < V.W && iy < V.H)
+                alphas[(size_t)iy * V.W + ix] = 1.0f - T[q];
+        }
+    }
 }
 
 // Test/debug: expand the weight store into (gid, pix, w) triples.
@@ -278,7 +264,7 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
     static int extra_lds = -1; // experiment knob: pad the workgroup's LDS footprint to cap co-residency
     if (extra_lds < 0)
         extra_lds = getenv("GWBP_BLEND_LDS") ? atoi(getenv("GWBP_BLEND_LDS")) : 0;
-    hipLaunchKernelGGL(k_blend, dim3(n_tiles), dim3(256), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d, W.counters,
+    hipLaunchKernelGGL(k_blend, dim3(n_tiles), dim3(64), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d, W.counters,
                        W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, alphas,
                        getenv("GWBP_ABLATE_BLEND") ? atoi(getenv("GWBP_ABLATE_BLEND")) : 0);
     hipLaunchKernelGGL(k_pool_stats, dim3(1), dim3(1), 0, s, W.shards, W.counters);

@@ -8,8 +8,8 @@
 //     every feature byte is read from HBM exactly once per view
 //   * a wave owns one (Gaussian, tile) record at a time (LDS work counter); the Gaussian is wave-uniform and
 //     lanes = channel pairs (ds_read_b64: conflict-free 512-B rows)
-//   * the record's {w, pixel} entries (up to four quarter lists in the weight store) are FLATTENED: lane s of load j
-//     fetches entry 64j + s with one 8-B load (it computes which quarter list its slot falls in), so a typical record
+//   * the record's {w, pixel} entries are contiguous in the weight store (k_blend writes a record's four quarter
+//     lists back to back): lane s of load j fetches entry 64j + s with one 8-B load, so a typical record
 //     (45 entries) costs ONE coalesced 512-B load.  The accumulate loop walks the entries in batches of 8 with
 //     compile-time lane selects: per pair 2 v_readlane (w, pixel) + 1 v_lshl_add (LDS address) + 1 ds_read_b64 +
 //     1 v_pk_fma_f32; the next batch's eight LDS reads are issued before the current batch's FMAs.
@@ -39,9 +39,8 @@ constexpr size_t kLdsBytes = (size_t)kSlabFloats * 4 + 16;
 
 struct Rec { // wave-uniform (SGPR) description of one (Gaussian, tile) record
     u32 gid;
-    u32 woff[4];
-    u32 base[4]; // exclusive prefix of the quarter entry counts
-    u32 T;       // entries in the record (1..256)
+    u32 woff; // first entry; the record's entries (all four quarters) are contiguous in the weight store
+    u32 T;    // entries in the record (1..256)
 };
 
 __device__ __forceinline__ float readlane_f(float v, int l)
@@ -136,26 +135,15 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
         const Header *hp = hbase + min(h, nh - 1);
         Rec r;
         r.gid = uniform(hp->gid);
-        const u32 counts = uniform(hp->counts);
-        u32 run = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            r.woff[q] = uniform(hp->woff[q]);
-            r.base[q] = run;
-            run += (counts >> (8 * q)) & 0xFFu;
-        }
-        r.T = run;
+        r.woff = uniform(hp->woff[0]);
+        const u32 c = uniform(hp->counts);
+        r.T = (c & 0xFFu) + ((c >> 8) & 0xFFu) + ((c >> 16) & 0xFFu) + (c >> 24);
         return r;
     };
-    // slot s of the record's flattened entry stream -> index into the weight pool
-    auto wslot = [&](const Rec &R, u32 s) -> u32 {
-        u32 off = R.woff[0] + s;
-        off = (s >= R.base[1]) ? R.woff[1] + (s - R.base[1]) : off;
-        off = (s >= R.base[2]) ? R.woff[2] + (s - R.base[2]) : off;
-        off = (s >= R.base[3]) ? R.woff[3] + (s - R.base[3]) : off;
-        return off;
-    };
-    auto prefetch = [&](const Rec &R, EV (&e)[2]) __attribute__((always_inline)) { // exactly 2 VMEM loads (slots 0..127, clamped to the last one)
+    // slot s of the record's entry stream -> index into the weight pool
+    auto wslot = [&](const Rec &R, u32 s) -> u32 { return R.woff + s; };
+    auto prefetch = [&](const Rec &R, EV (&e)[2]) __attribute__((always_inline)) {
+        // exactly 2 VMEM loads (slots 0..127, clamped to the last one); one coalesced 512-B read per 64 entries
         const u32 last = R.T ? R.T - 1 : 0u;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
