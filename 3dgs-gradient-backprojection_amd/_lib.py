@@ -33,7 +33,8 @@ class View(C.Structure):
 
 class Caps(C.Structure):
     _fields_ = [("n_gaussians", C.c_int64), ("isect_cap", C.c_int64), ("pair_cap", C.c_int64),
-                ("max_width", C.c_int32), ("max_height", C.c_int32)]
+                ("max_width", C.c_int32), ("max_height", C.c_int32), ("scatter_workgroups", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):

@@ -57,6 +57,12 @@ class ViewPipeline:
     def __init__(self, n_gaussians, width, height, device, engines=None):
         self.dev = torch.device(device)
         self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev) for _ in range(2)]
+        # leave 1/8 of the CUs to the overlapped front stages (measured optimum on MI355X, see include/gwbp.h)
+        cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        for e in self.eng:
+            if e.scatter_workgroups == 0:
+                e.scatter_workgroups = max(8, (cus * 7 // 8 + 7) // 8 * 8)
+                e.caps.scatter_workgroups = e.scatter_workgroups
         self.side = torch.cuda.Stream(device=self.dev)
         self.ev_front = [torch.cuda.Event() for _ in range(2)]
         self.ev_done = [torch.cuda.Event() for _ in range(2)]

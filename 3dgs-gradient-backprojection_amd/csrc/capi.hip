@@ -42,6 +42,7 @@ int make_layout(const gwbp_caps *c, Layout *L)
     L->n = c->n_gaussians;
     L->isect_cap = c->isect_cap;
     L->pair_cap = c->pair_cap;
+    L->scatter_wgs = c->scatter_workgroups > 0 ? c->scatter_workgroups : 0;
     const int tw = (c->max_width + kTile - 1) / kTile, th = (c->max_height + kTile - 1) / kTile;
     L->max_tiles = tw * th;
     L->n_scan_blocks = (int)((L->n + kScanBlock - 1) / kScanBlock);
@@ -53,7 +54,7 @@ int make_layout(const gwbp_caps *c, Layout *L)
         return at;
     };
     L->counters = take(sizeof(Counters));
-    L->shards = take((size_t)kShards * 64);
+    L->shards = take((size_t)(kShards + kQueues) * 64);
     L->g2d = take((size_t)L->n * sizeof(G2D));
     L->rect = take((size_t)L->n * sizeof(uint2));
     L->touched = take((size_t)L->n * sizeof(u32));

@@ -20,6 +20,7 @@ constexpr float kClampMargin = 0x1.333334p-2f; // 0.3 (x/z clamp margin in tan_f
 constexpr int kTile = GWBP_TILE;     // 16 x 16 pixels
 constexpr int kTilePix = 256;
 constexpr int kPage = 1024;          // weight-pool page (pairs) grabbed per (tile, wave) stream
+constexpr int kQueues = 8;           // scatter work queues, one per XCD class (blockIdx % 8), 64 B apart, after the shard heads
 constexpr int kShards = 32;          // independently counted regions of the weight pool (one head word per 64-B line)
 constexpr int kListPad = 8;          // every (record, quarter) list is padded to a multiple of 8 pairs
 constexpr int kSortItems = 4096;     // keys per sort block (256 threads x 16)
@@ -70,7 +71,7 @@ struct Layout {
     size_t counters, shards, g2d, rect, touched, blocksums, keys[2], vals[2], hist, digit_total, tile_offsets, hdr_count,
         headers, wpool;
     int64_t n, isect_cap, pair_cap;
-    int max_tiles, n_scan_blocks, n_sort_blocks;
+    int max_tiles, n_scan_blocks, n_sort_blocks, scatter_wgs;
 };
 
 struct Ws {
@@ -121,8 +122,8 @@ int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *ise
 int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, hipStream_t s);
 int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
                    int64_t fs_c, int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s);
-int launch_scatter_full(const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x, int D,
-                        float scale_f, float scale_d, float *F, float *d, hipStream_t s);
+int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
+                        int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s);
 int launch_render(const Layout &L, const Ws &W, const ViewDev &V, const float *colors, int D, float *out,
                   hipStream_t s);
 int launch_render_px(const Ws &W, const ViewDev &V, const float *colors, int D, float *out, float *alphas,

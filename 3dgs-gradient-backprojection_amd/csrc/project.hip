@@ -254,7 +254,7 @@ int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *
                    float *conics, hipStream_t s)
 {
     // counters and the pool shard heads are adjacent sub-buffers: one memset node
-    int rc = check_hip(hipMemsetAsync(W.counters, 0, (size_t)((char *)W.shards - (char *)W.counters) + kShards * 64, s),
+    int rc = check_hip(hipMemsetAsync(W.counters, 0, (size_t)((char *)W.shards - (char *)W.counters) + (kShards + kQueues) * 64, s),
                        "memset counters");
     if (rc)
         return rc;

@@ -305,7 +305,6 @@ static int chunk_pitch(int D)
 int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
                    int64_t fs_c, int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s)
 {
-    (void)L;
     const int n_tiles = V.tile_w * V.tile_h;
     const int n_tiles_pad = (n_tiles + 7) & ~7;
     const int n_chunks = (D + kChunk - 1) / kChunk;
@@ -328,7 +327,7 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const float *
     const bool full = (D % kChunk == 0) && fs_c == 1 && (fs_x % 4 == 0) && (fs_y % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(feats) & 15) == 0);
     if (full)
-        return launch_scatter_full(W, V, feats, fs_y, fs_x, D, scale_f, scale_d, F, d, s);
+        return launch_scatter_full(L, W, V, feats, fs_y, fs_x, D, scale_f, scale_d, F, d, s);
     else
         hipLaunchKernelGGL(k_scatter, dim3(n_tiles_pad * n_chunks), dim3(kScatterThreads), lds_bytes, s, V,
                            n_tiles_pad, n_chunks, pitch, W.tile_offsets, W.hdr_count, W.headers, W.wpool, feats, fs_y,

@@ -3,7 +3,8 @@
 //
 //   F[g, c0:c0+128] += sum_p w_g(p) * feats[p, c0:c0+128]        (backproject.py:127-131 via colors.grad)
 //
-// workgroup = (16x16 tile, 128-channel chunk), 1024 threads = 16 waves, one workgroup per CU (128 KB LDS):
+// work item = (16x16 tile, 128-channel chunk); 1024 threads = 16 waves, ONE PERSISTENT workgroup per CU (128 KB LDS)
+// pulling items from a per-XCD-class queue:
 //   * the tile's 256 px x 128 ch slab is staged once (eight 16-B loads per thread in flight, then eight LDS writes):
 //     every feature byte is read from HBM exactly once per view
 //   * a wave owns one (Gaussian, tile) record at a time (LDS work counter); the Gaussian is wave-uniform and
@@ -35,7 +36,7 @@ namespace {
 constexpr int kChunk = 128;
 constexpr int kThreads = 1024;
 constexpr int kSlabFloats = kTilePix * kChunk; // 32768 floats = 128 KB
-constexpr size_t kLdsBytes = (size_t)kSlabFloats * 4 + 16;
+constexpr size_t kLdsBytes = (size_t)kSlabFloats * 4 + 16; // slab + work counter + two item slots
 
 struct Rec { // wave-uniform (SGPR) description of one (Gaussian, tile) record
     u32 gid;
@@ -73,31 +74,45 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
     ViewDev V, int n_chunks, const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
     const Header *__restrict__ headers, const WPair *__restrict__ wpool, const float *__restrict__ feats,
     int64_t fs_y, int64_t fs_x, int D, float scale_f, float scale_d, float *__restrict__ F,
-    float *__restrict__ dsum_out, int dbg)
+    float *__restrict__ dsum_out, u32 *__restrict__ queues, int dbg)
 {
     constexpr int pitch = kChunk;
     // dynamic LDS only (no static __shared__ in front of it: the carve base stays 16-B aligned)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     u32 *s_next = reinterpret_cast<u32 *>(lds + kSlabFloats);
 
-    // XCD-aware decode: blocks b and b+8 share an XCD; one tile's chunks get the same b % 8 so the weight store is
-    // pulled from HBM once and re-read from that XCD's L2.
-    const u32 b = blockIdx.x;
-    const u32 x = b & 7u, sidx = b >> 3;
-    const int chunk = (int)(sidx % (u32)n_chunks);
-    const int tile = (int)((sidx / (u32)n_chunks) * 8u + x);
-    if (tile >= V.tile_w * V.tile_h)
-        return;
+    // PERSISTENT workgroups: the grid is one workgroup per CU; each pulls (tile, chunk) items from the work queue of
+    // its XCD class.  Blocks b and b+8 share an XCD, so class x = b % 8 owns the tiles t with t % 8 == x and a tile's
+    // chunks are consecutive items of one queue: the weight store is pulled from HBM once and re-read from that XCD's
+    // L2.  The next item is claimed (one returning atomic by thread 0) while the current slab loads are in flight --
+    // the vmcnt(0) the slab staging needs anyway covers it, so dynamic scheduling costs no extra wait.  Compared with
+    // one workgroup per item this removes ~105 workgroup launches per CU per view and keeps the CU's LDS claimed, so
+    // the overlapped front-stage kernels (ViewPipeline) can never take over a CU between two scatter workgroups.
+    const u32 xcls = blockIdx.x & 7u;
+    const int n_tiles = V.tile_w * V.tile_h;
+    const u32 n_items = (u32)((n_tiles - (int)xcls + 7) / 8) * (u32)n_chunks; // tiles of this class x chunks
+    u32 *queue = queues + xcls * 16;
+    u32 *s_item = s_next + 1; // two slots: iteration k reads [k & 1], thread 0 fills [(k + 1) & 1] meanwhile
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0)
+        s_item[0] = atomicAdd(queue, 1u);
+    __syncthreads();
+    for (u32 k = 0;; ++k) {
+    const u32 item = s_item[k & 1u];
+    if (item >= n_items)
+        break;
+    const int chunk = (int)(item % (u32)n_chunks);
+    const int tile = (int)((item / (u32)n_chunks) * 8u + xcls);
     const u32 nh = hdr_count[tile];
-    if (nh == 0)
-        return;
     const int tx = tile % V.tile_w, ty = tile / V.tile_w;
     const int c0 = chunk * kChunk;
-    const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0)
         *s_next = 0;
 
-    if (!(dbg & 4)) { // stage the 256 px x 128 ch slab: 32 float4 per pixel row
+    u32 nxt = 0;
+    if (threadIdx.x == 0)
+        nxt = atomicAdd(queue, 1u); // claim the next item; the value is only needed after the slab is staged
+    if (!(dbg & 4) && nh != 0) { // stage the 256 px x 128 ch slab: 32 float4 per pixel row
         constexpr int vpr = pitch >> 2;
         constexpr int kIt = kTilePix * vpr / kThreads; // 8
         float4 vals[kIt];
@@ -118,6 +133,8 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
             *reinterpret_cast<float4 *>(lds + p * pitch + 4 * v) = vals[it];
         }
     }
+    if (threadIdx.x == 0)
+        s_item[(k + 1u) & 1u] = nxt;
     __syncthreads();
 
     const Header *hbase = headers + tile_offsets[tile];
@@ -125,13 +142,13 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
     const char *slab = reinterpret_cast<const char *>(lds);
     const bool want_d = (chunk == 0) && (dsum_out != nullptr);
 
-    auto claim = [&]() -> u32 {
+    auto claim = [&]() __attribute__((always_inline)) -> u32 {
         u32 h = 0;
         if (lane == 0)
             h = atomicAdd(s_next, 1u);
         return uniform(h);
     };
-    auto load_rec = [&](u32 h) -> Rec { // scalar loads; an invalid claim re-reads the last header (never processed)
+    auto load_rec = [&](u32 h) __attribute__((always_inline)) -> Rec { // scalar loads; an invalid claim re-reads the last header (never processed)
         const Header *hp = hbase + min(h, nh - 1);
         Rec r;
         r.gid = uniform(hp->gid);
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
         return r;
     };
     // slot s of the record's entry stream -> index into the weight pool
-    auto wslot = [&](const Rec &R, u32 s) -> u32 { return R.woff + s; };
+    auto wslot = [&](const Rec &R, u32 s) __attribute__((always_inline)) -> u32 { return R.woff + s; };
     auto prefetch = [&](const Rec &R, EV (&e)[2]) __attribute__((always_inline)) {
         // exactly 2 VMEM loads (slots 0..127, clamped to the last one); one coalesced 512-B read per 64 entries
         const u32 last = R.T ? R.T - 1 : 0u;
@@ -235,47 +252,54 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
 
     EV eA[2] = {{0.f, 0u}, {0.f, 0u}}, eB[2] = {{0.f, 0u}, {0.f, 0u}};
     u32 h = claim();
-    if (h >= nh)
-        return;
-    Rec Rcur = load_rec(h);
-    prefetch(Rcur, eA);
-    h = claim();
-    bool vnxt = h < nh;
-    Rec Rnxt = load_rec(h);
-
-    // peeled first phase: no atomics issued yet, only loads(1) are younger than loads(0)
-    prefetch(Rnxt, eB);
-    h = claim();
-    bool vnn = h < nh;
-    Rec Rnn = load_rec(h);
-    wait_e<2>(eA);
-    process(Rcur, eA);
-    while (vnxt) {
-        // odd phase: current record's entries in eB; next record loads into eA
-        Rcur = Rnxt, Rnxt = Rnn, vnxt = vnn;
-        prefetch(Rnxt, eA);
+    if (h < nh) {
+        Rec Rcur = load_rec(h);
+        prefetch(Rcur, eA);
         h = claim();
-        vnn = h < nh;
-        Rnn = load_rec(h);
-        wait_e<4>(eB);
-        process(Rcur, eB);
-        if (!vnxt)
-            break;
-        // even phase: current in eA; next into eB
-        Rcur = Rnxt, Rnxt = Rnn, vnxt = vnn;
+        bool vnxt = h < nh;
+        Rec Rnxt = load_rec(h);
+
+        // peeled first phase: only loads(1) are guaranteed younger than loads(0) (atomics of a previous item are older)
         prefetch(Rnxt, eB);
         h = claim();
-        vnn = h < nh;
-        Rnn = load_rec(h);
-        wait_e<4>(eA);
+        bool vnn = h < nh;
+        Rec Rnn = load_rec(h);
+        wait_e<2>(eA);
         process(Rcur, eA);
+        while (vnxt) {
+            // odd phase: current record's entries in eB; next record loads into eA
+            Rcur = Rnxt, Rnxt = Rnn, vnxt = vnn;
+            prefetch(Rnxt, eA);
+            h = claim();
+            vnn = h < nh;
+            Rnn = load_rec(h);
+            wait_e<4>(eB);
+            process(Rcur, eB);
+            if (!vnxt)
+                break;
+            // even phase: current in eA; next into eB
+            Rcur = Rnxt, Rnxt = Rnn, vnxt = vnn;
+            prefetch(Rnxt, eB);
+            h = claim();
+            vnn = h < nh;
+            Rnn = load_rec(h);
+            wait_e<4>(eA);
+            process(Rcur, eA);
+        }
+        // The last prefetch (a clamped re-read for a record that does not exist) is still in flight and will write
+        // eA/eB's physical registers when it lands; hipcc considers those registers dead here and would reuse them for
+        // the next item's address arithmetic.  Drain before leaving the record loop (the slab staging of the next
+        // item needs vmcnt(0) anyway).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __syncthreads(); // every wave is done with this slab and work counter
+    } // item loop
 }
 
 } // namespace
 
-int launch_scatter_full(const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x, int D,
-                        float scale_f, float scale_d, float *F, float *d, hipStream_t s)
+int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
+                        int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s)
 {
     const int n_tiles = V.tile_w * V.tile_h;
     const int n_tiles_pad = (n_tiles + 7) & ~7;
@@ -290,9 +314,21 @@ int launch_scatter_full(const Ws &W, const ViewDev &V, const float *feats, int64
         attr_done = true;
     }
     const char *ab = getenv("GWBP_ABLATE"); // profiling ablation only (results are invalid when set)
-    hipLaunchKernelGGL(k_scatter_full, dim3(n_tiles_pad * n_chunks), dim3(kThreads), kLdsBytes, s, V, n_chunks,
-                       W.tile_offsets, W.hdr_count, W.headers, W.wpool, feats, fs_y, fs_x, D, scale_f, scale_d, F, d,
-                       ab ? atoi(ab) : 0);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return set_error(GWBP_EINVAL, "cannot query the device for the persistent scatter grid");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    (void)n_tiles_pad;
+    // persistent workgroups: one per CU by default (caps.scatter_workgroups overrides), a multiple of the 8 XCD classes
+    int grid = L.scatter_wgs > 0 ? L.scatter_wgs : n_cu;
+    grid = (grid + 7) & ~7;
+    hipLaunchKernelGGL(k_scatter_full, dim3(grid), dim3(kThreads), kLdsBytes, s, V, n_chunks, W.tile_offsets,
+                       W.hdr_count, W.headers, W.wpool, feats, fs_y, fs_x, D, scale_f, scale_d, F, d,
+                       W.shards + kShards * 16, ab ? atoi(ab) : 0);
     return check_hip(hipGetLastError(), "scatter_full launch");
 }
 

@@ -83,9 +83,12 @@ def main():
         if not st["overflow"]:
             break
         eng.grow(st)
-    eng2 = gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap)
-    pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng, eng2])
-    accum = pipe.accum
+    if args.serial:
+        pipe, accum = None, torch.zeros(32, dtype=torch.uint8, device=dev)
+    else:
+        eng2 = gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap)
+        pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng, eng2])
+        accum = pipe.accum
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     n_total = args.steps + args.warmup

@@ -51,8 +51,13 @@ typedef struct gwbp_view {
 typedef struct gwbp_caps {
     int64_t n_gaussians; /* N */
     int64_t isect_cap;   /* max (Gaussian, tile) intersections per view */
-    int64_t pair_cap;    /* max stored blend weights (floats) per view, incl. page slack */
+    int64_t pair_cap;    /* max stored weight-store entries (8 B each) per view, incl. page slack */
     int32_t max_width, max_height;
+    /* Tuning: number of persistent scatter workgroups (rounded up to a multiple of 8); 0 = one per CU.  When the
+     * front stages of the next view run concurrently on a second stream (ViewPipeline), 7/8 of the CUs balances the
+     * two streams best on MI355X (224: 4.74 ms/view vs 5.13 at 256 on C2). */
+    int32_t scatter_workgroups;
+    int32_t reserved;
 } gwbp_caps;
 
 /* Device-resident per-view counters, readable after the stream has drained (gwbp_read_stats). */

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.View) == 16 * 4 + 9 * 4 + 2 * 4 + 4 * 4
-    assert C.sizeof(_lib.Caps) == 8 * 3 + 4 * 2
+    assert C.sizeof(_lib.Caps) == 8 * 3 + 4 * 4
     assert C.sizeof(_lib.Stats) == 32
 
 
