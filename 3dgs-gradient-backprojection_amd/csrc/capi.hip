@@ -46,7 +46,7 @@ int make_layout(const gwbp_caps *c, Layout *L)
     const int tw = (c->max_width + kTile - 1) / kTile, th = (c->max_height + kTile - 1) / kTile;
     L->max_tiles = tw * th;
     L->n_scan_blocks = (int)((L->n + kScanBlock - 1) / kScanBlock);
-    L->n_sort_blocks = (int)((L->isect_cap + kSortItems - 1) / kSortItems);
+    L->n_sort_blocks = (int)(((L->isect_cap > L->n ? L->isect_cap : L->n) + kSortItems - 1) / kSortItems);
     size_t o = 0;
     auto take = [&](size_t bytes) {
         size_t at = o;
@@ -59,8 +59,12 @@ int make_layout(const gwbp_caps *c, Layout *L)
     L->rect = take((size_t)L->n * sizeof(uint2));
     L->touched = take((size_t)L->n * sizeof(u32));
     L->blocksums = take((size_t)(L->n_scan_blocks + 1) * sizeof(u32));
-    L->keys[0] = take((size_t)L->isect_cap * sizeof(u64));
-    L->keys[1] = take((size_t)L->isect_cap * sizeof(u64));
+    for (int i = 0; i < 2; ++i) {
+        L->dkeys[i] = take((size_t)L->n * sizeof(u32));
+        L->dvals[i] = take((size_t)L->n * sizeof(u32));
+    }
+    L->keys[0] = take((size_t)L->isect_cap * sizeof(u32));
+    L->keys[1] = take((size_t)L->isect_cap * sizeof(u32));
     L->vals[0] = take((size_t)L->isect_cap * sizeof(u32));
     L->vals[1] = take((size_t)L->isect_cap * sizeof(u32));
     L->hist = take((size_t)256 * L->n_sort_blocks * sizeof(u32));
@@ -91,8 +95,12 @@ int bind_workspace(const gwbp_caps *caps, void *ws, size_t bytes, Layout *L, Ws 
     W->rect = reinterpret_cast<uint2 *>(b + L->rect);
     W->touched = reinterpret_cast<u32 *>(b + L->touched);
     W->blocksums = reinterpret_cast<u32 *>(b + L->blocksums);
-    W->keys[0] = reinterpret_cast<u64 *>(b + L->keys[0]);
-    W->keys[1] = reinterpret_cast<u64 *>(b + L->keys[1]);
+    for (int i = 0; i < 2; ++i) {
+        W->dkeys[i] = reinterpret_cast<u32 *>(b + L->dkeys[i]);
+        W->dvals[i] = reinterpret_cast<u32 *>(b + L->dvals[i]);
+    }
+    W->keys[0] = reinterpret_cast<u32 *>(b + L->keys[0]);
+    W->keys[1] = reinterpret_cast<u32 *>(b + L->keys[1]);
     W->vals[0] = reinterpret_cast<u32 *>(b + L->vals[0]);
     W->vals[1] = reinterpret_cast<u32 *>(b + L->vals[1]);
     W->hist = reinterpret_cast<u32 *>(b + L->hist);

@@ -68,7 +68,7 @@ static_assert(sizeof(Counters) == sizeof(gwbp_stats), "Counters must mirror gwbp
 
 struct Layout {
     size_t total;
-    size_t counters, shards, g2d, rect, touched, blocksums, keys[2], vals[2], hist, digit_total, tile_offsets, hdr_count,
+    size_t counters, shards, g2d, rect, touched, blocksums, dkeys[2], dvals[2], keys[2], vals[2], hist, digit_total, tile_offsets, hdr_count,
         headers, wpool;
     int64_t n, isect_cap, pair_cap;
     int max_tiles, n_scan_blocks, n_sort_blocks, scatter_wgs;
@@ -81,8 +81,9 @@ struct Ws {
     uint2 *rect; // x = xmin | xmax<<16, y = ymin | ymax<<16
     u32 *touched;
     u32 *blocksums;
-    u64 *keys[2];
-    u32 *vals[2];
+    u32 *dkeys[2], *dvals[2]; // depth sort of the Gaussians: key = depth bits (0xFFFFFFFF if culled), value = index
+    u32 *keys[2];             // intersection sort: key = tile id
+    u32 *vals[2];             //                    value = Gaussian index
     u32 *hist;
     u32 *digit_total;
     u32 *tile_offsets;
@@ -105,18 +106,20 @@ struct ViewDev { // per-launch copy of gwbp_view (kernel argument, 128 B)
 };
 int make_view(const gwbp_view *v, const gwbp_caps *caps, ViewDev *out);
 
+// 8-bit passes of the tile-id sort of the intersections (the depth order comes from the Gaussian pre-sort)
 inline int sort_passes(int n_tiles)
 {
-    int tile_bits = 0;
+    int tile_bits = 1;
     while ((1 << tile_bits) < n_tiles)
         ++tile_bits;
-    return (32 + tile_bits + 7) / 8;
+    return (tile_bits + 7) / 8;
 }
 
 // stage launchers (one per .hip file)
 int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *means, const float *quats,
                    const float *scales, const float *opac, int32_t *radii, float *means2d, float *depths,
                    float *conics, hipStream_t s);
+int launch_emit(const Layout &L, const Ws &W, const ViewDev &V, const u32 *order, hipStream_t s);
 int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *isect_ids, int32_t *flatten_ids,
                     int32_t *tile_offsets, hipStream_t s);
 int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, hipStream_t s);

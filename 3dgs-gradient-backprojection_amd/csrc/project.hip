@@ -14,8 +14,8 @@ namespace gwbp {
 __global__ __launch_bounds__(kScanBlock) void k_project(
     int64_t N, ViewDev V, const float *__restrict__ means, const float *__restrict__ quats,
     const float *__restrict__ scales, const float *__restrict__ opac, G2D *__restrict__ g2d,
-    uint2 *__restrict__ rect, u32 *__restrict__ touched, u32 *__restrict__ blocksums, Counters *__restrict__ ctr,
-    int32_t *__restrict__ o_radii, float *__restrict__ o_means2d, float *__restrict__ o_depths,
+    uint2 *__restrict__ rect, u32 *__restrict__ touched, u32 *__restrict__ dkeys, u32 *__restrict__ dvals,
+    Counters *__restrict__ ctr, int32_t *__restrict__ o_radii, float *__restrict__ o_means2d, float *__restrict__ o_depths,
     float *__restrict__ o_conics)
 {
     const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
@@ -126,6 +126,9 @@ __global__ __launch_bounds__(kScanBlock) void k_project(
         gp[1] = make_float4(g.ca, g.cb, g.cc, __int_as_float(g.radius));
         rect[i] = rc;
         touched[i] = ntiles;
+        // depth-sort key: positive float bits order like unsigned integers; culled Gaussians go last
+        dkeys[i] = g.radius > 0 ? (u32)__float_as_int(g.depth) : 0xFFFFFFFFu;
+        dvals[i] = (u32)i;
         if (o_radii)
             o_radii[i] = g.radius;
         if (o_means2d)
@@ -136,27 +139,43 @@ __global__ __launch_bounds__(kScanBlock) void k_project(
             o_conics[3 * i] = g.ca, o_conics[3 * i + 1] = g.cb, o_conics[3 * i + 2] = g.cc;
     }
 
-    // block totals of tiles touched (for the scan) and of visible Gaussians
-    __shared__ u32 s_sum[kScanBlock / 64], s_vis[kScanBlock / 64];
-    u32 v = ntiles;
+    // visible-Gaussian count
+    __shared__ u32 s_vis[kScanBlock / 64];
+    const u64 visb = __ballot(g.radius > 0);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+        s_vis[wave] = (u32)__popcll(visb);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 vis = 0;
+#pragma unroll
+        for (int w = 0; w < kScanBlock / 64; ++w)
+            vis += s_vis[w];
+        if (vis)
+            atomicAdd(&ctr->n_visible, vis);
+    }
+}
+
+// Block totals of tiles touched, taken in DEPTH-SORTED Gaussian order (input of the scan that places the emit).
+__global__ __launch_bounds__(kScanBlock) void k_sorted_blocksums(int64_t N, const u32 *__restrict__ order,
+                                                                 const u32 *__restrict__ touched,
+                                                                 u32 *__restrict__ blocksums)
+{
+    const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
+    u32 v = (i < N) ? touched[order[i]] : 0u;
+    __shared__ u32 s_sum[kScanBlock / 64];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         v += __shfl_down(v, o, 64);
-    const u64 visb = __ballot(g.radius > 0);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
-        s_sum[wave] = v;
-        s_vis[wave] = (u32)__popcll(visb);
-    }
+    if ((threadIdx.x & 63) == 0)
+        s_sum[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
-        u32 tot = 0, vis = 0;
+        u32 tot = 0;
 #pragma unroll
         for (int w = 0; w < kScanBlock / 64; ++w)
-            tot += s_sum[w], vis += s_vis[w];
+            tot += s_sum[w];
         blocksums[blockIdx.x] = tot;
-        if (vis)
-            atomicAdd(&ctr->n_visible, vis);
     }
 }
 
@@ -207,19 +226,21 @@ __global__ __launch_bounds__(1024) void k_scan_blocksums(int nblk, u32 *__restri
     }
 }
 
-// isect_tiles emit: key = tile_id << 32 | depth bits, value = Gaussian index, in ascending Gaussian order so the
-// stable sort keeps gsplat's tie order.
-__global__ __launch_bounds__(kScanBlock) void k_emit(int64_t N, int tile_w, const G2D *__restrict__ g2d,
+// isect_tiles emit in depth-sorted Gaussian order: key = tile id, value = Gaussian index.  Because the Gaussians are
+// visited front to back (ties in ascending index), a STABLE sort by tile id alone afterwards yields gsplat's order
+// (tile, depth, index) -- 2 byte-passes over the intersections instead of 6 over 64-bit keys.
+__global__ __launch_bounds__(kScanBlock) void k_emit(int64_t N, int tile_w, const u32 *__restrict__ order,
                                                      const uint2 *__restrict__ rect,
                                                      const u32 *__restrict__ touched,
                                                      const u32 *__restrict__ blocksums,
-                                                     const Counters *__restrict__ ctr, u64 *__restrict__ keys,
+                                                     const Counters *__restrict__ ctr, u32 *__restrict__ keys,
                                                      u32 *__restrict__ vals)
 {
     if (ctr->overflow & 1u)
         return;
     const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
-    const u32 cnt = (i < N) ? touched[i] : 0u;
+    const u32 gid = (i < N) ? order[i] : 0u;
+    const u32 cnt = (i < N) ? touched[gid] : 0u;
     __shared__ u32 s_wave[kScanBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u32 incl = cnt;
@@ -238,15 +259,25 @@ __global__ __launch_bounds__(kScanBlock) void k_emit(int64_t N, int tile_w, cons
     if (cnt == 0)
         return;
     u32 pos = blocksums[blockIdx.x] + woff + incl - cnt;
-    const uint2 rc = rect[i];
+    const uint2 rc = rect[gid];
     const u32 x0 = rc.x & 0xFFFFu, x1 = rc.x >> 16, y0 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
-    const u32 dbits = (u32)__float_as_int(g2d[i].depth);
     for (u32 ty = y0; ty < y1; ++ty)
         for (u32 tx = x0; tx < x1; ++tx) {
-            keys[pos] = ((u64)(ty * (u32)tile_w + tx) << 32) | dbits;
-            vals[pos] = (u32)i;
+            keys[pos] = ty * (u32)tile_w + tx;
+            vals[pos] = gid;
             ++pos;
         }
+}
+
+int launch_emit(const Layout &L, const Ws &W, const ViewDev &V, const u32 *order, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sorted_blocksums, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, order, W.touched,
+                       W.blocksums);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, s, L.n_scan_blocks, W.blocksums, W.counters,
+                       (u32)L.isect_cap);
+    hipLaunchKernelGGL(k_emit, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, V.tile_w, order, W.rect, W.touched,
+                       W.blocksums, W.counters, W.keys[0], W.vals[0]);
+    return check_hip(hipGetLastError(), "emit launch");
 }
 
 int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *means, const float *quats,
@@ -261,11 +292,7 @@ int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *
     if (L.n == 0)
         return GWBP_OK;
     hipLaunchKernelGGL(k_project, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, V, means, quats, scales, opac,
-                       W.g2d, W.rect, W.touched, W.blocksums, W.counters, radii, means2d, depths, conics);
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, s, L.n_scan_blocks, W.blocksums, W.counters,
-                       (u32)L.isect_cap);
-    hipLaunchKernelGGL(k_emit, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, V.tile_w, W.g2d, W.rect,
-                       W.touched, W.blocksums, W.counters, W.keys[0], W.vals[0]);
+                       W.g2d, W.rect, W.touched, W.dkeys[0], W.dvals[0], W.counters, radii, means2d, depths, conics);
     return check_hip(hipGetLastError(), "project launch");
 }
 

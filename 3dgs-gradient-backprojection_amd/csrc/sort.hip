@@ -1,15 +1,19 @@
-// sort.hip -- stable LSD radix sort of the (tile_id << 32 | depth_bits, gaussian_id) intersection pairs and the
-// per-tile offset table.
+// sort.hip -- two-level stable LSD radix sort producing gsplat's (tile, depth, index) order, and the per-tile
+// offset table.
 //
-// Replaces cub::DeviceRadixSort::SortPairs + isect_offset_encode inside gsplat 1.4.0's rasterization().
-// The number of pairs n lives in device memory (Counters::n_isect), so every kernel is launched for the caller's
-// capacity and idle blocks exit at once: no host read-back between projection and blend.
+// Replaces cub::DeviceRadixSort::SortPairs on 64-bit (tile << 32 | depth) keys + isect_offset_encode inside gsplat
+// 1.4.0's rasterization():
+//   level 1  the N Gaussians are sorted ONCE by depth bits (4 byte-passes over N 32-bit keys; culled ones last)
+//   emit     intersections are emitted in that order (project.hip: k_emit), key = tile id
+//   level 2  stable sort of the intersections by tile id only (ceil(tile_bits / 8) = 2 byte-passes at 1600x1060)
+// -> (tile, depth, index) order with 2 passes over the 4.4 M intersections instead of 6 passes over 64-bit keys.
+// The number of intersections lives in device memory (Counters::n_isect), so the level-2 kernels are launched for
+// the caller's capacity and idle blocks exit at once: no host read-back between projection and blend.
 //
 // Per 8-bit pass: (1) k_hist   - per-block digit histogram, hist[digit][block]
 //                 (2) k_scan   - one workgroup per digit: exclusive scan over blocks + digit total
-//                 (3) k_radix_scatter- wave-striped stable ranking (ballot "match" per digit, per-wave LDS counters),
-//                                keys/values kept in registers between ranking and scatter.
-// Only bits [0, 32 + tile_bits) are sorted (6 passes at 1600x1060).
+//                 (3) k_radix_scatter - wave-striped stable ranking (ballot "match" per digit, per-wave LDS
+//                                counters), keys/values kept in registers between ranking and scatter.
 #include "gwbp_dev.h"
 
 namespace gwbp {
@@ -19,11 +23,10 @@ constexpr int kItemsPerThread = kSortItems / kSortThreads; // 16
 constexpr int kWaves = kSortThreads / 64;
 constexpr int kWaveItems = kSortItems / kWaves; // 1024 keys per wave segment
 
-__global__ __launch_bounds__(kSortThreads) void k_hist(const u64 *__restrict__ keys,
-                                                       const Counters *__restrict__ ctr, int shift, int nblk,
-                                                       u32 *__restrict__ hist)
+__global__ __launch_bounds__(kSortThreads) void k_hist(const u32 *__restrict__ keys, const u32 *__restrict__ n_dev,
+                                                       u32 n_host, int shift, int nblk, u32 *__restrict__ hist)
 {
-    const u32 n = ctr->n_isect;
+    const u32 n = n_dev ? *n_dev : n_host;
     const u32 base = blockIdx.x * (u32)kSortItems;
     __shared__ u32 s_h[256];
     s_h[threadIdx.x] = 0;
@@ -78,14 +81,15 @@ __global__ __launch_bounds__(256) void k_scan(int nblk, u32 *__restrict__ hist, 
         digit_total[blockIdx.x] = s_carry;
 }
 
-__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u64 *__restrict__ keys_in,
-                                                          const u32 *__restrict__ vals_in,
-                                                          u64 *__restrict__ keys_out, u32 *__restrict__ vals_out,
-                                                          const Counters *__restrict__ ctr, int shift, int nblk,
-                                                          const u32 *__restrict__ hist,
-                                                          const u32 *__restrict__ digit_total)
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u32 *__restrict__ keys_in,
+                                                                const u32 *__restrict__ vals_in,
+                                                                u32 *__restrict__ keys_out,
+                                                                u32 *__restrict__ vals_out,
+                                                                const u32 *__restrict__ n_dev, u32 n_host, int shift,
+                                                                int nblk, const u32 *__restrict__ hist,
+                                                                const u32 *__restrict__ digit_total)
 {
-    const u32 n = ctr->n_isect;
+    const u32 n = n_dev ? *n_dev : n_host;
     const u32 base = blockIdx.x * (u32)kSortItems;
     if (base >= n)
         return;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u64 *__res
     }
     __syncthreads();
 
-    u64 key[kItemsPerThread];
+    u32 key[kItemsPerThread];
     u32 val[kItemsPerThread];
     u32 rank[kItemsPerThread];
     const u32 seg = base + wave * (u32)kWaveItems;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u64 *__res
     for (int it = 0; it < kItemsPerThread; ++it) {
         const u32 idx = seg + it * 64 + lane;
         const bool valid = idx < n;
-        key[it] = valid ? keys_in[idx] : ~0ull;
+        key[it] = valid ? keys_in[idx] : ~0u;
         val[it] = valid ? vals_in[idx] : 0u;
         const u32 dg = (u32)(key[it] >> shift) & 0xFFu;
         u64 peers = __ballot(valid);
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u64 *__res
 }
 
 // isect_offset_encode: offsets[t] = first index whose tile >= t; offsets[n_tiles] = n.
-__global__ __launch_bounds__(256) void k_tile_offsets(const u64 *__restrict__ keys,
+__global__ __launch_bounds__(256) void k_tile_offsets(const u32 *__restrict__ keys,
                                                       const Counters *__restrict__ ctr, int n_tiles,
                                                       u32 *__restrict__ offsets)
 {
@@ -182,8 +186,8 @@ __global__ __launch_bounds__(256) void k_tile_offsets(const u64 *__restrict__ ke
     }
     if (i >= n)
         return;
-    const int t = (int)(keys[i] >> 32);
-    const int tp = (i == 0) ? -1 : (int)(keys[i - 1] >> 32);
+    const int t = (int)keys[i];
+    const int tp = (i == 0) ? -1 : (int)keys[i - 1];
     for (int tt = tp + 1; tt <= t; ++tt)
         offsets[tt] = i;
     if (i == n - 1)
@@ -191,15 +195,16 @@ __global__ __launch_bounds__(256) void k_tile_offsets(const u64 *__restrict__ ke
             offsets[tt] = n;
 }
 
-__global__ void k_export_sorted(const u64 *__restrict__ keys, const u32 *__restrict__ vals,
-                                const Counters *__restrict__ ctr, int64_t cap, int64_t *__restrict__ o_keys,
-                                int32_t *__restrict__ o_vals)
+// gsplat's meta: isect_ids = tile << 32 | depth bits (rebuilt from the tile key and the Gaussian's depth), flatten_ids
+__global__ void k_export_sorted(const u32 *__restrict__ keys, const u32 *__restrict__ vals,
+                                const G2D *__restrict__ g2d, const Counters *__restrict__ ctr, int64_t cap,
+                                int64_t *__restrict__ o_keys, int32_t *__restrict__ o_vals)
 {
     const u32 n = ctr->n_isect;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
         const bool in = i < (int64_t)n;
         if (o_keys)
-            o_keys[i] = in ? (int64_t)keys[i] : -1;
+            o_keys[i] = in ? (int64_t)(((u64)keys[i] << 32) | (u32)__float_as_int(g2d[vals[i]].depth)) : -1;
         if (o_vals)
             o_vals[i] = in ? (int32_t)vals[i] : -1;
     }
@@ -212,25 +217,41 @@ __global__ void k_copy_u32(const u32 *__restrict__ src, int32_t *__restrict__ ds
         dst[i] = (int32_t)src[i];
 }
 
+static void radix_passes(const Ws &W, u32 *const keys[2], u32 *const vals[2], const u32 *n_dev, u32 n_host, int nblk,
+                         int passes, hipStream_t s)
+{
+    for (int p = 0; p < passes; ++p) {
+        const int in = p & 1, out = in ^ 1;
+        hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(kSortThreads), 0, s, keys[in], n_dev, n_host, p * 8, nblk, W.hist);
+        hipLaunchKernelGGL(k_scan, dim3(256), dim3(256), 0, s, nblk, W.hist, W.digit_total);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(kSortThreads), 0, s, keys[in], vals[in], keys[out],
+                           vals[out], n_dev, n_host, p * 8, nblk, W.hist, W.digit_total);
+    }
+}
+
 int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *isect_ids, int32_t *flatten_ids,
                     int32_t *tile_offsets, hipStream_t s)
 {
     const int n_tiles = V.tile_w * V.tile_h;
-    const int passes = sort_passes(n_tiles);
-    const int nblk = L.n_sort_blocks;
-    for (int p = 0; p < passes; ++p) {
-        const int in = p & 1, out = in ^ 1;
-        hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(kSortThreads), 0, s, W.keys[in], W.counters, p * 8, nblk, W.hist);
-        hipLaunchKernelGGL(k_scan, dim3(256), dim3(256), 0, s, nblk, W.hist, W.digit_total);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(kSortThreads), 0, s, W.keys[in], W.vals[in], W.keys[out],
-                           W.vals[out], W.counters, p * 8, nblk, W.hist, W.digit_total);
+    if (L.n > 0) {
+        // level 1: Gaussians by depth (4 passes -> the result is back in buffer 0)
+        const int nblk1 = (int)((L.n + kSortItems - 1) / kSortItems);
+        radix_passes(W, W.dkeys, W.dvals, nullptr, (u32)L.n, nblk1, 4, s);
+        // emit intersections front to back
+        int rc = launch_emit(L, W, V, W.dvals[0], s);
+        if (rc)
+            return rc;
     }
+    // level 2: intersections by tile id
+    const int passes = sort_passes(n_tiles);
+    const int nblk2 = (int)((L.isect_cap + kSortItems - 1) / kSortItems);
+    radix_passes(W, W.keys, W.vals, &W.counters->n_isect, 0u, nblk2, passes, s);
     const int fin = passes & 1;
     const int ob = (int)((L.isect_cap + 255) / 256);
     hipLaunchKernelGGL(k_tile_offsets, dim3(ob > 0 ? ob : 1), dim3(256), 0, s, W.keys[fin], W.counters, n_tiles,
                        W.tile_offsets);
     if (isect_ids || flatten_ids)
-        hipLaunchKernelGGL(k_export_sorted, dim3(1024), dim3(256), 0, s, W.keys[fin], W.vals[fin], W.counters,
+        hipLaunchKernelGGL(k_export_sorted, dim3(1024), dim3(256), 0, s, W.keys[fin], W.vals[fin], W.g2d, W.counters,
                            L.isect_cap, isect_ids, flatten_ids);
     if (tile_offsets)
         hipLaunchKernelGGL(k_copy_u32, dim3((n_tiles + 256) / 256), dim3(256), 0, s, W.tile_offsets, tile_offsets,

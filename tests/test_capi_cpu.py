@@ -39,8 +39,9 @@ def test_workspace_size_and_argument_validation():
     n = C.c_size_t(0)
     caps = _lib.Caps(1_000_000, 16_000_000, 217_088_000, 1600, 1060)
     assert lib.gwbp_workspace_size(C.byref(caps), C.byref(n)) == 0
-    # g2d 32 B + rect 8 B + touched 4 B per Gaussian; keys/vals double-buffered 24 B + header 64 B per isect; 8 B/pair
-    expect = 1_000_000 * 44 + 16_000_000 * 88 + 217_088_000 * 8
+    # g2d 32 + rect 8 + touched 4 + depth-sort key/value ping-pong 16 B per Gaussian; tile key/value ping-pong 16 B +
+    # header 64 B per intersection; 8 B per weight-store entry
+    expect = 1_000_000 * 60 + 16_000_000 * 80 + 217_088_000 * 8
     assert expect < n.value < expect * 1.02
     bad = _lib.Caps(-1, 16, 1 << 20, 64, 64)
     assert lib.gwbp_workspace_size(C.byref(bad), C.byref(n)) == -1
