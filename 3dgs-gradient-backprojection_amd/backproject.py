@@ -10,6 +10,7 @@ added once after the reduction, then normalisation is row-local (backproject.py:
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Callable, Dict, Optional, Sequence
 
@@ -57,11 +58,12 @@ class ViewPipeline:
     def __init__(self, n_gaussians, width, height, device, engines=None):
         self.dev = torch.device(device)
         self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev) for _ in range(2)]
-        # leave 1/8 of the CUs to the overlapped front stages (measured optimum on MI355X, see include/gwbp.h)
+        # leave 1/16 of the CUs to the overlapped front stages (measured balance point on MI355X, see include/gwbp.h;
+        # GWBP_PIPE_WGS overrides for tuning)
         cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
         for e in self.eng:
             if e.scatter_workgroups == 0:
-                e.scatter_workgroups = max(8, (cus * 7 // 8 + 7) // 8 * 8)
+                e.scatter_workgroups = int(os.environ.get("GWBP_PIPE_WGS", max(8, (cus * 15 // 16 + 7) // 8 * 8)))
                 e.caps.scatter_workgroups = e.scatter_workgroups
         self.side = torch.cuda.Stream(device=self.dev)
         self.ev_front = [torch.cuda.Event() for _ in range(2)]
