@@ -33,6 +33,7 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
 {
     __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
     __shared__ float4 s_b[kBatch]; // ca, cb, cc, strip mask
+    __shared__ float s_thr[kBatch]; // ln(255 o) + margin: sigma above this cannot reach alpha >= 1/255
 
     const int tile = blockIdx.x;
     const int tx = tile % V.tile_w, ty = tile / V.tile_w;
@@ -48,14 +49,17 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
     const u32 shard_base = shard * shard_cap;
     u32 *shard_head = shards + shard * 16;
 
-    float T[4], py[4];
-    bool done[4];
+    // Per-pixel state.  T = 0 encodes "terminated or outside the image": a pixel with T = 0 can never produce a valid
+    // pair again (T (1 - alpha) = 0 <= 1e-4), so no separate done flag -- and none of the scalar mask bookkeeping a
+    // bool per lane costs (the first version of this loop issued more SALU than VALU instructions).  Tout keeps the
+    // transmittance to report (1 - Tout = alpha map), which the terminating Gaussian must not change.
+    float T[4], Tout[4], py[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int iy = iy0 + 4 * q;
         py[q] = (float)iy + 0.5f;
-        T[q] = 1.0f;
-        done[q] = !(ix < V.W && iy < V.H);
+        T[q] = (ix < V.W && iy < V.H) ? 1.0f : 0.0f;
+        Tout[q] = 1.0f;
     }
     u32 page_pos = 0, page_left = 0, npairs = 0, hdr_n = 0; // wave-uniform
     bool dead = false;                                     // wave-uniform: pool exhausted
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
         u32 alive = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            alive |= (__ballot(!done[q]) != 0ull ? 1u : 0u) << q;
+            alive |= (__ballot(T[q] > 0.f) != 0ull ? 1u : 0u) << q;
         if (alive == 0)
             break;
         const u32 bn = min((u32)kBatch, end - batch);
@@ -99,6 +103,8 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
             }
             s_a[lane] = make_float4(a.x, a.y, a.z, __int_as_float((int)gid));
             s_b[lane] = make_float4(b.x, b.y, b.z, __int_as_float((int)smask));
+            // alpha = o exp(-sigma) >= 1/255  <=>  sigma <= ln(255 o); 1e-3 absorbs the error of __logf and exp_neg
+            s_thr[lane] = L + 1e-3f;
         }
         // single wave: LDS operations of one wave complete in program order, no barrier needed
 
@@ -108,26 +114,32 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
             if (sm == 0)
                 continue; // this Gaussian cannot reach any live quarter of the tile
             const float4 a = s_a[j];
+            const float thr = s_thr[j];
             const float dx = a.x - px;
             const float adx = b.x * dx, bdx = b.y * dx; // shared by the four quarters (same column)
             u64 m[4];
             float w[4];
             bool valid[4];
-            // Per-lane control flow is branch-free (selects); the only branches are wave-uniform.
+            // Per-lane control flow is branch-free and flag-free (float selects); the only branches are wave-uniform.
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 m[q] = 0ull, w[q] = 0.f, valid[q] = false;
                 if ((sm >> q) & 1u) {
                     const float dy = a.y - py[q];
                     const float sigma = __builtin_fmaf(bdx, dy, 0.5f * __builtin_fmaf(adx, dx, (b.z * dy) * dy));
+                    // no live pixel of this quarter lies inside the alpha >= 1/255 ellipse: skip exp / T / ballot
+                    if (__ballot(T[q] > 0.f && sigma <= thr) == 0ull)
+                        continue;
                     const float alpha = __builtin_fminf(kAlphaMax, a.z * exp_neg(-__builtin_fmaxf(sigma, 0.f)));
-                    const bool ok = !done[q] && (sigma >= 0.f) && (alpha >= kAlphaMin);
+                    const float a1 = sigma >= 0.f ? alpha : 0.f;            // sigma < 0: skipped
+                    const bool ok = a1 >= kAlphaMin;                         // alpha < 1/255: skipped
                     const float next_T = T[q] * (1.0f - alpha);
-                    const bool term = ok && (next_T <= kTMin); // the terminating Gaussian is NOT counted
-                    valid[q] = ok && !term;
+                    const float t = ok ? next_T : 0.f;
+                    valid[q] = t > kTMin;                                    // T' <= 1e-4: terminates, NOT counted
+                    const float T_else = ok ? 0.f : T[q];                    // ok but not valid -> terminated
                     w[q] = alpha * T[q];
-                    T[q] = valid[q] ? next_T : T[q];
-                    done[q] = done[q] || term;
+                    T[q] = valid[q] ? next_T : T_else;
+                    Tout[q] = valid[q] ? next_T : Tout[q];
                     m[q] = __ballot(valid[q]);
                 }
             }
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
                     alive = 0;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        alive |= (__ballot(!done[q]) != 0ull ? 1u : 0u) << q;
+                        alive |= (__ballot(T[q] > 0.f) != 0ull ? 1u : 0u) << q;
                     if (alive == 0)
                         break;
                 }
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
         for (int q = 0; q < 4; ++q) {
             const int iy = iy0 + 4 * q;
             if (ix < V.W && iy < V.H)
-                alphas[(size_t)iy * V.W + ix] = 1.0f - T[q];
+                alphas[(size_t)iy * V.W + ix] = 1.0f - Tout[q];
         }
     }
 }
