@@ -119,11 +119,10 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
             const float adx = b.x * dx, bdx = b.y * dx; // shared by the four quarters (same column)
             u64 m[4];
             float w[4];
-            bool valid[4];
             // Per-lane control flow is branch-free and flag-free (float selects); the only branches are wave-uniform.
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                m[q] = 0ull, w[q] = 0.f, valid[q] = false;
+                m[q] = 0ull, w[q] = 0.f;
                 if ((sm >> q) & 1u) {
                     const float dy = a.y - py[q];
                     const float sigma = __builtin_fmaf(bdx, dy, 0.5f * __builtin_fmaf(adx, dx, (b.z * dy) * dy));
@@ -135,12 +134,12 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
                     const bool ok = a1 >= kAlphaMin;                         // alpha < 1/255: skipped
                     const float next_T = T[q] * (1.0f - alpha);
                     const float t = ok ? next_T : 0.f;
-                    valid[q] = t > kTMin;                                    // T' <= 1e-4: terminates, NOT counted
+                    const bool valid = t > kTMin;                            // T' <= 1e-4: terminates, NOT counted
                     const float T_else = ok ? 0.f : T[q];                    // ok but not valid -> terminated
                     w[q] = alpha * T[q];
-                    T[q] = valid[q] ? next_T : T_else;
-                    Tout[q] = valid[q] ? next_T : Tout[q];
-                    m[q] = __ballot(valid[q]);
+                    T[q] = valid ? next_T : T_else;
+                    Tout[q] = valid ? next_T : Tout[q];
+                    m[q] = __ballot(valid);
                 }
             }
             if ((m[0] | m[1] | m[2] | m[3]) == 0ull) {
@@ -179,7 +178,7 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
             if (!dead && !(dbg & 1)) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (valid[q]) {
+                    if ((m[q] >> lane) & 1ull) { // exec = the quarter's ballot mask
                         WPair e;
                         e.w = w[q], e.pix = (u32)(q * 64 + lane);
                         wpool[page_pos + base[q] + mbcnt(m[q])] = e;
