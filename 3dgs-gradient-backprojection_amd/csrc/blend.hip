@@ -29,13 +29,14 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
                                               const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
                                               Counters *__restrict__ ctr, Header *__restrict__ headers,
                                               u32 *__restrict__ hdr_count, WPair *__restrict__ wpool, u32 pair_cap,
-                                              u32 *__restrict__ shards, float *__restrict__ alphas, int dbg)
+                                              u32 *__restrict__ shards, const u32 *__restrict__ tile_order, float *__restrict__ alphas,
+                                              int dbg)
 {
     __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
     __shared__ float4 s_b[kBatch]; // ca, cb, cc, strip mask
     __shared__ float s_thr[kBatch]; // ln(255 o) + margin: sigma above this cannot reach alpha >= 1/255
 
-    const int tile = blockIdx.x;
+    const int tile = (int)tile_order[blockIdx.x]; // longest lists first
     const int tx = tile % V.tile_w, ty = tile / V.tile_w;
     const int lane = threadIdx.x;
     const int ix = tx * kTile + (lane & 15), iy0 = ty * kTile + (lane >> 4);
@@ -276,7 +277,7 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
     if (extra_lds < 0)
         extra_lds = getenv("GWBP_BLEND_LDS") ? atoi(getenv("GWBP_BLEND_LDS")) : 0;
     hipLaunchKernelGGL(k_blend, dim3(n_tiles), dim3(64), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d, W.counters,
-                       W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, alphas,
+                       W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, W.tile_order, alphas,
                        getenv("GWBP_ABLATE_BLEND") ? atoi(getenv("GWBP_ABLATE_BLEND")) : 0);
     hipLaunchKernelGGL(k_pool_stats, dim3(1), dim3(1), 0, s, W.shards, W.counters);
     return check_hip(hipGetLastError(), "blend launch");

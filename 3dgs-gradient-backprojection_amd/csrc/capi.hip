@@ -70,6 +70,7 @@ int make_layout(const gwbp_caps *c, Layout *L)
     L->hist = take((size_t)256 * L->n_sort_blocks * sizeof(u32));
     L->digit_total = take(256 * sizeof(u32));
     L->tile_offsets = take((size_t)(L->max_tiles + 1) * sizeof(u32));
+    L->tile_order = take((size_t)L->max_tiles * sizeof(u32));
     L->hdr_count = take((size_t)L->max_tiles * sizeof(u32));
     L->headers = take((size_t)L->isect_cap * sizeof(Header));
     L->wpool = take((size_t)L->pair_cap * sizeof(WPair));
@@ -106,6 +107,7 @@ int bind_workspace(const gwbp_caps *caps, void *ws, size_t bytes, Layout *L, Ws 
     W->hist = reinterpret_cast<u32 *>(b + L->hist);
     W->digit_total = reinterpret_cast<u32 *>(b + L->digit_total);
     W->tile_offsets = reinterpret_cast<u32 *>(b + L->tile_offsets);
+    W->tile_order = reinterpret_cast<u32 *>(b + L->tile_order);
     W->hdr_count = reinterpret_cast<u32 *>(b + L->hdr_count);
     W->headers = reinterpret_cast<Header *>(b + L->headers);
     W->wpool = reinterpret_cast<WPair *>(b + L->wpool);

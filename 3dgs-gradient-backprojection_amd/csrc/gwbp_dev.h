@@ -68,7 +68,7 @@ static_assert(sizeof(Counters) == sizeof(gwbp_stats), "Counters must mirror gwbp
 
 struct Layout {
     size_t total;
-    size_t counters, shards, g2d, rect, touched, blocksums, dkeys[2], dvals[2], keys[2], vals[2], hist, digit_total, tile_offsets, hdr_count,
+    size_t counters, shards, g2d, rect, touched, blocksums, dkeys[2], dvals[2], keys[2], vals[2], hist, digit_total, tile_offsets, tile_order, hdr_count,
         headers, wpool;
     int64_t n, isect_cap, pair_cap;
     int max_tiles, n_scan_blocks, n_sort_blocks, scatter_wgs;
@@ -87,6 +87,7 @@ struct Ws {
     u32 *hist;
     u32 *digit_total;
     u32 *tile_offsets;
+    u32 *tile_order; // tiles by descending list length (heavy tiles start first in k_blend)
     u32 *hdr_count;
     Header *headers;
     WPair *wpool;

@@ -53,9 +53,8 @@ typedef struct gwbp_caps {
     int64_t isect_cap;   /* max (Gaussian, tile) intersections per view */
     int64_t pair_cap;    /* max stored weight-store entries (8 B each) per view, incl. page slack */
     int32_t max_width, max_height;
-    /* Tuning: number of persistent scatter workgroups (rounded up to a multiple of 8); 0 = one per CU.  When the
-     * front stages of the next view run concurrently on a second stream (ViewPipeline), leaving 1/16 - 1/8 of the CUs
-     * to them balances the two streams on MI355X (C2: 4.62 ms/view at 240 vs 4.71 at 256 and 4.83 at 216). */
+    /* Tuning: number of persistent scatter workgroups (rounded up to a multiple of 8); 0 = one per CU (default and
+     * measured optimum on MI355X, also when the next view's front stages overlap on a second stream). */
     int32_t scatter_workgroups;
     int32_t reserved;
 } gwbp_caps;
