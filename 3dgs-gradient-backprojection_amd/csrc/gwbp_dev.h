@@ -22,7 +22,7 @@ constexpr int kTilePix = 256;
 constexpr int kPage = 1024;          // weight-pool page (pairs) grabbed per (tile, wave) stream
 constexpr int kQueues = 8;           // scatter work queues, one per XCD class (blockIdx % 8), 64 B apart, after the shard heads
 constexpr int kShards = 32;          // independently counted regions of the weight pool (one head word per 64-B line)
-constexpr int kListPad = 8;          // every (record, quarter) list is padded to a multiple of 8 pairs
+constexpr int kListPad = 8;          // every record's entry list is zero-padded to a multiple of kListPad entries
 constexpr int kSortItems = 4096;     // keys per sort block (256 threads x 16)
 constexpr int kScanBlock = 256;      // Gaussians per project/emit block
 

@@ -170,30 +170,34 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
     float2 acc;
     // n in 1..64 entries held by lanes 0..n-1 of ev (lanes >= n: w = 0, pix = any valid pixel)
     auto run_vec = [&](const EV &ev, u32 n) __attribute__((always_inline)) {
-        float2 fa[8], fb[8];
+        // Batches of kB entries, two in flight: the next batch's LDS reads are issued before the current batch's FMAs.
+        // Lane selects are compile-time constants; exits are wave-uniform.  Lists are padded to kB entries with {0, 0}.
+        constexpr int kB = kListPad;
+        float2 fa[kB], fb[kB];
 #define GWBP_ISSUE8(B, f)                                                                                             \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                     \
-        f[j] = *reinterpret_cast<const float2 *>(slab + ((readlane_u(ev.pix, 8 * (B) + j) << 9) + lane_base));
+    _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                    \
+        f[j] = *reinterpret_cast<const float2 *>(slab + ((readlane_u(ev.pix, kB * (B) + j) << 9) + lane_base));
 #define GWBP_FMA8(B, f)                                                                                               \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                     \
+    _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                    \
     {                                                                                                                 \
-        const float w = readlane_f(ev.w, 8 * (B) + j);                                                                \
+        const float w = readlane_f(ev.w, kB * (B) + j);                                                               \
         acc.x = __builtin_fmaf(w, f[j].x, acc.x);                                                                     \
         acc.y = __builtin_fmaf(w, f[j].y, acc.y);                                                                     \
     }
+        constexpr int kNB = 64 / kB;
         GWBP_ISSUE8(0, fa)
 #pragma unroll
-        for (int B = 0; B < 8; B += 2) { // compile-time lane selects; uniform exits
-            const bool m1 = 8u * (B + 1) < n;
+        for (int B = 0; B < kNB; B += 2) {
+            const bool m1 = (u32)kB * (B + 1) < n;
             if (m1) {
                 GWBP_ISSUE8(B + 1, fb)
             }
             GWBP_FMA8(B, fa)
             if (!m1)
                 break;
-            const bool m2 = 8u * (B + 2) < n;
-            if (m2 && B + 2 < 8) {
-                GWBP_ISSUE8((B + 2) & 7, fa)
+            const bool m2 = (u32)kB * (B + 2) < n;
+            if (m2 && B + 2 < kNB) {
+                GWBP_ISSUE8((B + 2) & (kNB - 1), fa)
             }
             GWBP_FMA8(B + 1, fb)
             if (!m2)
