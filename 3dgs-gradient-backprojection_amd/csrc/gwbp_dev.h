@@ -127,7 +127,7 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
 int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
                    int64_t fs_c, int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s);
 int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
-                        int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s);
+                        int64_t fs_c, int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s);
 int launch_render(const Layout &L, const Ws &W, const ViewDev &V, const float *colors, int D, float *out,
                   hipStream_t s);
 int launch_render_px(const Ws &W, const ViewDev &V, const float *colors, int D, float *out, float *alphas,

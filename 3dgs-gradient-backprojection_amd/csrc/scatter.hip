@@ -324,10 +324,11 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const float *
             return rc;
         attr_done = true;
     }
+    // fast paths (scatter_full.hip): D % 128 == 0 with channel-contiguous, 16-B aligned maps, or D <= 64 with any strides
     const bool full = (D % kChunk == 0) && fs_c == 1 && (fs_x % 4 == 0) && (fs_y % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(feats) & 15) == 0);
-    if (full)
-        return launch_scatter_full(L, W, V, feats, fs_y, fs_x, D, scale_f, scale_d, F, d, s);
+    if (full || D <= 64)
+        return launch_scatter_full(L, W, V, feats, fs_y, fs_x, fs_c, D, scale_f, scale_d, F, d, s);
     else
         hipLaunchKernelGGL(k_scatter, dim3(n_tiles_pad * n_chunks), dim3(kScatterThreads), lds_bytes, s, V,
                            n_tiles_pad, n_chunks, pitch, W.tile_offsets, W.hdr_count, W.headers, W.wpool, feats, fs_y,

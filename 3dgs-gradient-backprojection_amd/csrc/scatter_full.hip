@@ -70,16 +70,20 @@ __device__ __forceinline__ void wait_e(EV (&e)[2])
                  : "memory");
 }
 
+// SMALL = false: D % 128 == 0, 128-channel chunks, lanes = channel pairs (ds_read_b64 + v_pk_fma_f32).
+// SMALL = true : D <= 64 (C1 D = 32, C5 D = 16, the drop-in's 3-channel denominator pass), one chunk, lane l = channel l
+//                (ds_read_b32 + v_fmac), any feature-map strides, slab pitch = D rounded up to 4 floats.
+template <bool SMALL>
 __global__ __launch_bounds__(kThreads) void k_scatter_full(
     ViewDev V, int n_chunks, const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
     const Header *__restrict__ headers, const WPair *__restrict__ wpool, const float *__restrict__ feats,
-    int64_t fs_y, int64_t fs_x, int D, float scale_f, float scale_d, float *__restrict__ F,
-    float *__restrict__ dsum_out, u32 *__restrict__ queues, int dbg)
+    int64_t fs_y, int64_t fs_x, int64_t fs_c, int pitch_rt, int D, float scale_f, float scale_d,
+    float *__restrict__ F, float *__restrict__ dsum_out, u32 *__restrict__ queues, int dbg)
 {
-    constexpr int pitch = kChunk;
+    const int pitch = SMALL ? pitch_rt : kChunk;
     // dynamic LDS only (no static __shared__ in front of it: the carve base stays 16-B aligned)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    u32 *s_next = reinterpret_cast<u32 *>(lds + kSlabFloats);
+    u32 *s_next = reinterpret_cast<u32 *>(lds + kTilePix * pitch);
 
     // PERSISTENT workgroups: the grid is one workgroup per CU; each pulls (tile, chunk) items from the work queue of
     // its XCD class.  Blocks b and b+8 share an XCD, so class x = b % 8 owns the tiles t with t % 8 == x and a tile's
@@ -112,25 +116,38 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
     u32 nxt = 0;
     if (threadIdx.x == 0)
         nxt = atomicAdd(queue, 1u); // claim the next item; the value is only needed after the slab is staged
-    if (!(dbg & 4) && nh != 0) { // stage the 256 px x 128 ch slab: 32 float4 per pixel row
-        constexpr int vpr = pitch >> 2;
-        constexpr int kIt = kTilePix * vpr / kThreads; // 8
-        float4 vals[kIt];
+    if (!(dbg & 4) && nh != 0) {
+        if constexpr (SMALL) { // 256 px x pitch floats, element-wise (any strides, zero past D or past the image)
+            const int total = kTilePix * pitch;
+            for (int idx = threadIdx.x; idx < total; idx += kThreads) {
+                const int p = idx / pitch, c = idx - p * pitch;
+                const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
+                float val = 0.f;
+                if (ix < V.W && iy < V.H && c < D)
+                    val = feats[(int64_t)iy * fs_y + (int64_t)ix * fs_x + (int64_t)c * fs_c];
+                lds[idx] = val;
+            }
+        } else { // stage the 256 px x 128 ch slab: 32 float4 per pixel row
+            constexpr int vpr = kChunk >> 2;
+            constexpr int kIt = kTilePix * vpr / kThreads; // 8
+            float4 vals[kIt];
 #pragma unroll
-        for (int it = 0; it < kIt; ++it) {
-            const int idx = it * kThreads + threadIdx.x;
-            const int p = idx / vpr, v = idx - p * vpr;
-            const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
-            // pixels past the image edge are never referenced by an entry: load a clamped (valid) address instead
-            // of branching, so the eight loads of a thread are all in flight before the first LDS write
-            const int cx_ = min(ix, V.W - 1), cy_ = min(iy, V.H - 1);
-            vals[it] = *reinterpret_cast<const float4 *>(feats + (int64_t)cy_ * fs_y + (int64_t)cx_ * fs_x + c0 + 4 * v);
-        }
+            for (int it = 0; it < kIt; ++it) {
+                const int idx = it * kThreads + threadIdx.x;
+                const int p = idx / vpr, v = idx - p * vpr;
+                const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
+                // pixels past the image edge are never referenced by an entry: load a clamped (valid) address
+                // instead of branching, so the eight loads of a thread are all in flight before the first LDS write
+                const int cx_ = min(ix, V.W - 1), cy_ = min(iy, V.H - 1);
+                vals[it] =
+                    *reinterpret_cast<const float4 *>(feats + (int64_t)cy_ * fs_y + (int64_t)cx_ * fs_x + c0 + 4 * v);
+            }
 #pragma unroll
-        for (int it = 0; it < kIt; ++it) {
-            const int idx = it * kThreads + threadIdx.x;
-            const int p = idx / vpr, v = idx - p * vpr;
-            *reinterpret_cast<float4 *>(lds + p * pitch + 4 * v) = vals[it];
+            for (int it = 0; it < kIt; ++it) {
+                const int idx = it * kThreads + threadIdx.x;
+                const int p = idx / vpr, v = idx - p * vpr;
+                *reinterpret_cast<float4 *>(lds + p * kChunk + 4 * v) = vals[it];
+            }
         }
     }
     if (threadIdx.x == 0)
@@ -138,7 +155,9 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
     __syncthreads();
 
     const Header *hbase = headers + tile_offsets[tile];
-    const u32 lane_base = (u32)(2 * lane * sizeof(float)); // byte offset of this lane's channel pair inside a row
+    // byte offset of this lane's channel (pair) inside a pixel row; idle lanes of the small path re-read the last channel
+    const u32 lane_base = SMALL ? (u32)(min(lane, pitch - 1) * sizeof(float)) : (u32)(2 * lane * sizeof(float));
+    const u32 row_bytes = (u32)pitch * (u32)sizeof(float);
     const char *slab = reinterpret_cast<const char *>(lds);
     const bool want_d = (chunk == 0) && (dsum_out != nullptr);
 
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
             issue_e(e[j], wpool + wslot(R, min((u32)(64 * j + lane), last)));
     };
 
-    float2 acc;
+    float2 acc = make_float2(0.f, 0.f);
     // n in 1..64 entries held by lanes 0..n-1 of ev (lanes >= n: w = 0, pix = any valid pixel)
     auto run_vec = [&](const EV &ev, u32 n) __attribute__((always_inline)) {
         // Batches of kB entries, two in flight: the next batch's LDS reads are issued before the current batch's FMAs.
@@ -176,13 +195,20 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
         float2 fa[kB], fb[kB];
 #define GWBP_ISSUE8(B, f)                                                                                             \
     _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                    \
-        f[j] = *reinterpret_cast<const float2 *>(slab + ((readlane_u(ev.pix, kB * (B) + j) << 9) + lane_base));
+    {                                                                                                                 \
+        const u32 px_ = readlane_u(ev.pix, kB * (B) + j);                                                             \
+        if constexpr (SMALL)                                                                                          \
+            f[j].x = *reinterpret_cast<const float *>(slab + (px_ * row_bytes + lane_base));                          \
+        else                                                                                                          \
+            f[j] = *reinterpret_cast<const float2 *>(slab + ((px_ << 9) + lane_base));                                \
+    }
 #define GWBP_FMA8(B, f)                                                                                               \
     _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                    \
     {                                                                                                                 \
         const float w = readlane_f(ev.w, kB * (B) + j);                                                               \
         acc.x = __builtin_fmaf(w, f[j].x, acc.x);                                                                     \
-        acc.y = __builtin_fmaf(w, f[j].y, acc.y);                                                                     \
+        if constexpr (!SMALL)                                                                                         \
+            acc.y = __builtin_fmaf(w, f[j].y, acc.y);                                                                 \
     }
         constexpr int kNB = 64 / kB;
         GWBP_ISSUE8(0, fa)
@@ -231,19 +257,32 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
                 run_vec(ev, n);
             }
         }
-        const float a0 = acc.x * scale_f, a1 = acc.y * scale_f;
         float *Fg = F + (int64_t)R.gid * D + c0;
-        { // channels c0 + [0, 64)
-            const int src = lane >> 1;
-            const float a = __shfl(a0, src, 64), bb = __shfl(a1, src, 64);
-            if (!(dbg & 1))
-                atomicAdd(Fg + lane, (lane & 1) ? bb : a);
-        }
-        { // channels c0 + [64, 128)
-            const int src = 32 + (lane >> 1);
-            const float a = __shfl(a0, src, 64), bb = __shfl(a1, src, 64);
-            if (!(dbg & 1))
-                atomicAdd(Fg + 64 + lane, (lane & 1) ? bb : a);
+        if constexpr (SMALL) { // lane l = channel l: one atomic instruction (always issued, lanes >= D masked off)
+            if (lane < D) {
+                if (!(dbg & 1))
+                    atomicAdd(Fg + lane, acc.x * scale_f);
+                else
+                    __builtin_nontemporal_store(acc.x * scale_f, Fg + lane);
+            }
+        } else {
+            const float a0 = acc.x * scale_f, a1 = acc.y * scale_f;
+            { // channels c0 + [0, 64)
+                const int src = lane >> 1;
+                const float a = __shfl(a0, src, 64), bb = __shfl(a1, src, 64);
+                if (!(dbg & 1))
+                    atomicAdd(Fg + lane, (lane & 1) ? bb : a);
+                else
+                    __builtin_nontemporal_store((lane & 1) ? bb : a, Fg + lane); // ablation: same VMEM count
+            }
+            { // channels c0 + [64, 128)
+                const int src = 32 + (lane >> 1);
+                const float a = __shfl(a0, src, 64), bb = __shfl(a1, src, 64);
+                if (!(dbg & 1))
+                    atomicAdd(Fg + 64 + lane, (lane & 1) ? bb : a);
+                else
+                    __builtin_nontemporal_store((lane & 1) ? bb : a, Fg + 64 + lane);
+            }
         }
         if (want_d) {
 #pragma unroll
@@ -277,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
             h = claim();
             vnn = h < nh;
             Rnn = load_rec(h);
-            wait_e<4>(eB);
+            wait_e<SMALL ? 3 : 4>(eB);
             process(Rcur, eB);
             if (!vnxt)
                 break;
@@ -287,7 +326,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
             h = claim();
             vnn = h < nh;
             Rnn = load_rec(h);
-            wait_e<4>(eA);
+            wait_e<SMALL ? 3 : 4>(eA);
             process(Rcur, eA);
         }
         // The last prefetch (a clamped re-read for a record that does not exist) is still in flight and will write
@@ -303,16 +342,22 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
 } // namespace
 
 int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
-                        int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s)
+                        int64_t fs_c, int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s)
 {
-    const int n_tiles = V.tile_w * V.tile_h;
-    const int n_tiles_pad = (n_tiles + 7) & ~7;
-    const int n_chunks = D / kChunk;
+    const bool small = D <= 64;
+    const int n_chunks = small ? 1 : D / kChunk;
+    const int pitch = small ? ((D + 3) & ~3) : kChunk;
+    const size_t lds_bytes = (size_t)kTilePix * pitch * sizeof(float) + 16; // slab + work counter + two item slots
     static bool attr_done = false; // benign race: idempotent
     if (!attr_done) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_full),
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_full<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes),
                            "scatter_full LDS attribute");
+        if (rc)
+            return rc;
+        rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_full<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16),
+                       "scatter_small LDS attribute");
         if (rc)
             return rc;
         attr_done = true;
@@ -326,13 +371,19 @@ int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const fl
             return set_error(GWBP_EINVAL, "cannot query the device for the persistent scatter grid");
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    (void)n_tiles_pad;
-    // persistent workgroups: one per CU by default (caps.scatter_workgroups overrides), a multiple of the 8 XCD classes
-    int grid = L.scatter_wgs > 0 ? L.scatter_wgs : n_cu;
+    // persistent workgroups: one per CU (two for the small-D path whose slab is <= 64 KB); caps.scatter_workgroups
+    // overrides; always a multiple of the 8 XCD classes
+    int grid = L.scatter_wgs > 0 ? L.scatter_wgs : (small ? 2 * n_cu : n_cu);
     grid = (grid + 7) & ~7;
-    hipLaunchKernelGGL(k_scatter_full, dim3(grid), dim3(kThreads), kLdsBytes, s, V, n_chunks, W.tile_offsets,
-                       W.hdr_count, W.headers, W.wpool, feats, fs_y, fs_x, D, scale_f, scale_d, F, d,
-                       W.shards + kShards * 16, ab ? atoi(ab) : 0);
+    u32 *queues = W.shards + kShards * 16;
+    if (small)
+        hipLaunchKernelGGL(k_scatter_full<true>, dim3(grid), dim3(kThreads), lds_bytes, s, V, n_chunks, W.tile_offsets,
+                           W.hdr_count, W.headers, W.wpool, feats, fs_y, fs_x, fs_c, pitch, D, scale_f, scale_d, F, d,
+                           queues, ab ? atoi(ab) : 0);
+    else
+        hipLaunchKernelGGL(k_scatter_full<false>, dim3(grid), dim3(kThreads), lds_bytes, s, V, n_chunks,
+                           W.tile_offsets, W.hdr_count, W.headers, W.wpool, feats, fs_y, fs_x, fs_c, pitch, D, scale_f,
+                           scale_d, F, d, queues, ab ? atoi(ab) : 0);
     return check_hip(hipGetLastError(), "scatter_full launch");
 }
 
