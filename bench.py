@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="feature maps cycled through (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=1)
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
     ap.add_argument("--serial", action="store_true", help="one stream, no overlap of front(v+1) with scatter(v)")
     args = ap.parse_args()
 
@@ -46,11 +47,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -134,7 +139,7 @@ def main():
     accum.zero_()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -144,14 +149,14 @@ def main():
         if i + 1 < n_total:
             front(i + 1)
         scatter(i)
-    if world > 1:
+    if use_dist:
         gsbp_amd.reduce_partials(F, d)
     barrier()
     elapsed = time.perf_counter() - t0
 
     stats = gsbp_amd.Engine.decode_stats(accum)
     tt = torch.tensor([elapsed, float(stats["n_pairs"]), float(stats["overflow"])], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
@@ -205,10 +210,14 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder,
                                                args.cpu_views)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        line = json.dumps(out)
+    else:
+        line = None
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        print(line, flush=True)  # the ONE JSON line, after any RCCL teardown chatter
 
 
 def cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder, n_views):
