@@ -19,7 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 EXPORTS = [
     "gwbp_version", "gwbp_last_error_string", "gwbp_workspace_size", "gwbp_project", "gwbp_bin_sort",
-    "gwbp_blend_weights", "gwbp_scatter", "gwbp_render", "gwbp_render_pixels", "gwbp_sh_colors",
+    "gwbp_blend_weights", "gwbp_scatter", "gwbp_scatter_upsampled", "gwbp_render", "gwbp_render_pixels", "gwbp_sh_colors",
     "gwbp_backproject_view", "gwbp_finalize",
     "gwbp_accumulate_stats", "gwbp_read_stats", "gwbp_dump_pairs",
 ]
@@ -72,10 +72,12 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise GwbpError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU or PyTorch fallback for this path)")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(os.environ.get("GWBP_LIB", LIB_PATH))  # GWBP_LIB: developer knob for A/B builds of the same ABI
         L.gwbp_version.restype = C.c_char_p
         L.gwbp_last_error_string.restype = C.c_char_p
         for name in EXPORTS[2:]:
+            if "GWBP_LIB" in os.environ and not hasattr(L, name):
+                continue  # an older A/B build; calling the missing entry point still raises
             getattr(L, name).restype = C.c_int
         _lib = L
     return _lib

@@ -88,7 +88,7 @@ class ViewPipeline:
         self.pending[self.i_front] = view
         self.i_front += 1
 
-    def scatter(self, feats, F, d, scale_f=1.0, scale_d=1.0, t0=None, t1=None):
+    def scatter(self, feats, F, d, scale_f=1.0, scale_d=1.0, t0=None, t1=None, upsample=None):
         """t0/t1: optional timing events recorded right around the scatter launch (after the cross-stream wait)."""
         i = self.i_scatter
         b = i % 2
@@ -97,7 +97,7 @@ class ViewPipeline:
         e = self.eng[b]
         if t0 is not None:
             t0.record(main)
-        e.scatter(self.pending.pop(i), feats, F, d, scale_f, scale_d)
+        e.scatter(self.pending.pop(i), feats, F, d, scale_f, scale_d, upsample=upsample)
         if t1 is not None:
             t1.record(main)
         e.accumulate_stats(self.accum)
@@ -112,7 +112,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                          feature_fn: Callable[[int], torch.Tensor], dim: int, reduction: str = "sum",
                          encoder: Optional[torch.Tensor] = None, engine: Optional[Engine] = None,
                          views: Optional[Sequence[int]] = None, view_fn=None, pipeline: bool = True,
-                         return_partials: bool = False, verbose: bool = False):
+                         return_partials: bool = False, verbose: bool = False, upsample: Optional[str] = None):
     """Build the [N, dim_out] per-Gaussian feature field.
 
     means/quats/scales/opacities: post-activation Gaussians (backproject.py:55-57), device tensors.
@@ -120,6 +120,9 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     LSeg/DINO forward of backproject.py:102-113 / :236-249).
     reduction: "sum" (lseg, backproject.py:127,145) or "mean" (dino, backproject.py:263,283).
     encoder [dim, dim_out]: backproject_compressed.py:127 (feats @ encoder before back-projection).
+    upsample="nearest": feature_fn returns the network's LOW-RESOLUTION map [h,w,dim] (dino patch tokens,
+    backproject.py:242-243); the nearest upsampling to (height, width) of backproject.py:244-248 happens inside the
+    scatter kernel's addressing instead of materialising an [H,W,dim] map per view.
     views: explicit list of view indices for this rank (default: interleaved shard over the process group).
     view_fn: injection point for the per-view accumulate (tests drive the sharding/reduction logic on CPU).
     pipeline: overlap the front stages of view v+1 with the scatter of view v (ViewPipeline).
@@ -155,7 +158,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                 feats = feature_fn(v)
                 if encoder is not None:
                     feats = feats @ encoder
-                pipe.scatter(feats, F, d, sf, sd)
+                pipe.scatter(feats, F, d, sf, sd, upsample=upsample)
             stats = pipe.stats()
         else:
             accum = torch.zeros(32, dtype=torch.uint8, device=dev)
@@ -164,7 +167,13 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                 if encoder is not None:
                     feats = feats @ encoder
                 view = eng.view(vm_host[v], K_host, width, height)
-                eng.backproject_view(view, means, quats, scales, opacities, feats, F, d, sf, sd)
+                if upsample is None:
+                    eng.backproject_view(view, means, quats, scales, opacities, feats, F, d, sf, sd)
+                else:
+                    eng.project(view, means, quats, scales, opacities)
+                    eng.bin_sort(view)
+                    eng.blend_weights(view)
+                    eng.scatter(view, feats, F, d, sf, sd, upsample=upsample)
                 eng.accumulate_stats(accum)
             stats = Engine.decode_stats(accum)  # synchronises
         if stats["overflow"]:

@@ -215,9 +215,8 @@ int gwbp_blend_weights(const gwbp_caps *caps, void *workspace, size_t workspace_
     return launch_blend(L, W, V, alphas, static_cast<hipStream_t>(stream));
 }
 
-int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
-                 const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c, int32_t D, float scale_f,
-                 float scale_d, float *F, float *d, void *stream)
+static int scatter_impl(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                        const FeatMap &M, int32_t D, float scale_f, float scale_d, float *F, float *d, void *stream)
 {
     Layout L;
     Ws W;
@@ -227,12 +226,30 @@ int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
         return rc;
     if ((rc = make_view(view_host, caps, &V)))
         return rc;
-    if ((rc = check_feats(feats, fs_y, fs_x, fs_c, D)))
+    if ((rc = check_feats(M.p, M.fs_y, M.fs_x, M.fs_c, D)))
         return rc;
     if (!F && L.n > 0)
         return set_error(GWBP_EINVAL, "null F");
-    return launch_scatter(L, W, V, feats, fs_y, fs_x, fs_c, D, scale_f, scale_d, F, d,
-                          static_cast<hipStream_t>(stream));
+    return launch_scatter(L, W, V, M, D, scale_f, scale_d, F, d, static_cast<hipStream_t>(stream));
+}
+
+int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                 const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c, int32_t D, float scale_f,
+                 float scale_d, float *F, float *d, void *stream)
+{
+    const FeatMap M{feats, fs_y, fs_x, fs_c, nullptr, nullptr};
+    return scatter_impl(caps, workspace, workspace_bytes, view_host, M, D, scale_f, scale_d, F, d, stream);
+}
+
+int gwbp_scatter_upsampled(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
+                           const gwbp_view *view_host, const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c,
+                           int32_t D, const int32_t *ymap, const int32_t *xmap, float scale_f, float scale_d, float *F,
+                           float *d, void *stream)
+{
+    if (!ymap || !xmap)
+        return set_error(GWBP_EINVAL, "gwbp_scatter_upsampled needs both index maps");
+    const FeatMap M{feats, fs_y, fs_x, fs_c, ymap, xmap};
+    return scatter_impl(caps, workspace, workspace_bytes, view_host, M, D, scale_f, scale_d, F, d, stream);
 }
 
 int gwbp_render(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
@@ -304,7 +321,8 @@ int gwbp_backproject_view(const gwbp_caps *caps, void *workspace, size_t workspa
         return rc;
     if ((rc = launch_blend(L, W, V, nullptr, s)))
         return rc;
-    return launch_scatter(L, W, V, feats, fs_y, fs_x, fs_c, D, scale_f, scale_d, F, d, s);
+    const FeatMap M{feats, fs_y, fs_x, fs_c, nullptr, nullptr};
+    return launch_scatter(L, W, V, M, D, scale_f, scale_d, F, d, s);
 }
 
 int gwbp_finalize(int64_t N, int32_t D, const float *F, const float *d, float *out, void *stream)

@@ -124,10 +124,23 @@ int launch_emit(const Layout &L, const Ws &W, const ViewDev &V, const u32 *order
 int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *isect_ids, int32_t *flatten_ids,
                     int32_t *tile_offsets, hipStream_t s);
 int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, hipStream_t s);
-int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
-                   int64_t fs_c, int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s);
-int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
-                        int64_t fs_c, int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s);
+// A 2-D feature map as the scatter kernels address it: feats[row(y)*fs_y + col(x)*fs_x + c*fs_c] (strides in floats).
+// ymap/xmap (device, optional) send an output pixel to the row/column of a lower-resolution map: the
+// F.interpolate(mode="nearest") of backproject.py:244-248 without materialising the upsampled map.
+struct FeatMap {
+    const float *p;
+    int64_t fs_y, fs_x, fs_c;
+    const int32_t *ymap, *xmap;
+    __host__ __device__ __forceinline__ int64_t pixel(int iy, int ix) const
+    {
+        const int64_t yy = ymap ? ymap[iy] : iy, xx = xmap ? xmap[ix] : ix;
+        return yy * fs_y + xx * fs_x;
+    }
+};
+int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
+                   float scale_d, float *F, float *d, hipStream_t s);
+int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
+                        float scale_d, float *F, float *d, hipStream_t s);
 int launch_render(const Layout &L, const Ws &W, const ViewDev &V, const float *colors, int D, float *out,
                   hipStream_t s);
 int launch_render_px(const Ws &W, const ViewDev &V, const float *colors, int D, float *out, float *alphas,

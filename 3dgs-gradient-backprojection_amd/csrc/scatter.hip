@@ -44,9 +44,10 @@ __device__ __forceinline__ int readlane_i(int v, u32 l) { return __builtin_amdgc
 __global__ __launch_bounds__(kScatterThreads) void k_scatter(
     ViewDev V, int n_tiles_pad, int n_chunks, int pitch, const u32 *__restrict__ tile_offsets,
     const u32 *__restrict__ hdr_count, const Header *__restrict__ headers, const WPair *__restrict__ wpool,
-    const float *__restrict__ feats, int64_t fs_y, int64_t fs_x, int64_t fs_c, int D, float scale_f, float scale_d,
-    float *__restrict__ F, float *__restrict__ dsum_out)
+    FeatMap M, int D, float scale_f, float scale_d, float *__restrict__ F, float *__restrict__ dsum_out)
 {
+    const float *__restrict__ feats = M.p;
+    const int64_t fs_x = M.fs_x, fs_y = M.fs_y, fs_c = M.fs_c;
     // dynamic LDS only (no static __shared__ in front of it: keeps the carve base 16-B aligned);
     // layout: [256][pitch] floats, then the work counter
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_scatter(
             const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ix < V.W && iy < V.H && 4 * v < cw)
-                val = *reinterpret_cast<const float4 *>(feats + (int64_t)iy * fs_y + (int64_t)ix * fs_x + c0 + 4 * v);
+                val = *reinterpret_cast<const float4 *>(feats + M.pixel(iy, ix) + c0 + 4 * v);
             *reinterpret_cast<float4 *>(lds + p * pitch + 4 * v) = val;
         }
     } else {
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_scatter(
             const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
             float val = 0.f;
             if (ix < V.W && iy < V.H && c < cw)
-                val = feats[(int64_t)iy * fs_y + (int64_t)ix * fs_x + (int64_t)(c0 + c) * fs_c];
+                val = feats[M.pixel(iy, ix) + (int64_t)(c0 + c) * fs_c];
             lds[p * pitch + c] = val;
         }
     }
@@ -302,8 +303,8 @@ static int chunk_pitch(int D)
     return (p + 3) & ~3; // multiple of 4 floats: 16-B LDS rows, even for the b64 channel pairs
 }
 
-int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
-                   int64_t fs_c, int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s)
+int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
+                   float scale_d, float *F, float *d, hipStream_t s)
 {
     const int n_tiles = V.tile_w * V.tile_h;
     const int n_tiles_pad = (n_tiles + 7) & ~7;
@@ -324,15 +325,13 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const float *
             return rc;
         attr_done = true;
     }
-    // fast paths (scatter_full.hip): D % 128 == 0 with channel-contiguous, 16-B aligned maps, or D <= 64 with any strides
-    const bool full = (D % kChunk == 0) && fs_c == 1 && (fs_x % 4 == 0) && (fs_y % 4 == 0) &&
-                      ((reinterpret_cast<uintptr_t>(feats) & 15) == 0);
-    if (full || D <= 64)
-        return launch_scatter_full(L, W, V, feats, fs_y, fs_x, fs_c, D, scale_f, scale_d, F, d, s);
+    // fast paths (scatter_full.hip): D % 128 == 0 or D <= 64, any strides
+    if (D % kChunk == 0 || D <= 64)
+        return launch_scatter_full(L, W, V, M, D, scale_f, scale_d, F, d, s);
     else
         hipLaunchKernelGGL(k_scatter, dim3(n_tiles_pad * n_chunks), dim3(kScatterThreads), lds_bytes, s, V,
-                           n_tiles_pad, n_chunks, pitch, W.tile_offsets, W.hdr_count, W.headers, W.wpool, feats, fs_y,
-                           fs_x, fs_c, D, scale_f, scale_d, F, d);
+                           n_tiles_pad, n_chunks, pitch, W.tile_offsets, W.hdr_count, W.headers, W.wpool, M, D, scale_f,
+                           scale_d, F, d);
     return check_hip(hipGetLastError(), "scatter launch");
 }
 

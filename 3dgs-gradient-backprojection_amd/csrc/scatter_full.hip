@@ -1,5 +1,7 @@
-// scatter_full.hip -- k_scatter_full: the D % 128 == 0, channel-contiguous fast path of the weighted
-// scatter-accumulate (C2/C4/C5-input: D = 512 / 768 / 1024); semantics identical to k_scatter (scatter.hip).
+// scatter_full.hip -- k_scatter_full: the D % 128 == 0 (and D <= 64) fast path of the weighted scatter-accumulate
+// (C2/C4/C5-input: D = 512 / 768 / 1024; dino 384); semantics identical to k_scatter (scatter.hip).  Channel-contiguous
+// maps are staged with 16-B loads, any other strides element-wise; optional row/column maps address a low-resolution
+// feature map (nearest upsampling, backproject.py:244-248).
 //
 //   F[g, c0:c0+128] += sum_p w_g(p) * feats[p, c0:c0+128]        (backproject.py:127-131 via colors.grad)
 //
@@ -76,10 +78,12 @@ __device__ __forceinline__ void wait_e(EV (&e)[2])
 template <bool SMALL>
 __global__ __launch_bounds__(kThreads) void k_scatter_full(
     ViewDev V, int n_chunks, const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
-    const Header *__restrict__ headers, const WPair *__restrict__ wpool, const float *__restrict__ feats,
-    int64_t fs_y, int64_t fs_x, int64_t fs_c, int pitch_rt, int D, float scale_f, float scale_d,
-    float *__restrict__ F, float *__restrict__ dsum_out, u32 *__restrict__ queues, int dbg)
+    const Header *__restrict__ headers, const WPair *__restrict__ wpool, FeatMap M, int vec_ok, int pitch_rt, int D,
+    float scale_f, float scale_d, float *__restrict__ F, float *__restrict__ dsum_out, u32 *__restrict__ queues,
+    int dbg)
 {
+    const float *__restrict__ feats = M.p;
+    const int64_t fs_c = M.fs_c;
     const int pitch = SMALL ? pitch_rt : kChunk;
     // dynamic LDS only (no static __shared__ in front of it: the carve base stays 16-B aligned)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
         s_item[0] = atomicAdd(queue, 1u);
     __syncthreads();
     for (u32 k = 0;; ++k) {
-    const u32 item = s_item[k & 1u];
+    const u32 item = uniform(s_item[k & 1u]); // wave-uniform by construction: keep every derived address scalar
     if (item >= n_items)
         break;
     const int chunk = (int)(item % (u32)n_chunks);
@@ -124,23 +128,52 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
                 const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
                 float val = 0.f;
                 if (ix < V.W && iy < V.H && c < D)
-                    val = feats[(int64_t)iy * fs_y + (int64_t)ix * fs_x + (int64_t)c * fs_c];
+                    val = feats[M.pixel(iy, ix) + (int64_t)c * fs_c];
                 lds[idx] = val;
+            }
+        } else if (!vec_ok) {
+            // any strides (e.g. the channel-major [D,H,W] map that permute(1,2,0) of backproject.py:249 hands over):
+            // lane = 8 pixels of a tile row x 8 channels -> 32-B runs of a channel plane on the load side, a 4-way
+            // bank conflict (2x a ds_write_b32) on the LDS side; 32 dwords per thread, eight in flight
+            constexpr int kIt = kSlabFloats / kThreads; // 32
+            const int pl = threadIdx.x & 7, cl = (threadIdx.x >> 3) & 7, rest = threadIdx.x >> 6; // 16 waves
+#pragma unroll 1
+            for (int it0 = 0; it0 < kIt; it0 += 8) {
+                float vals[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int u = (it0 + j) * 16 + rest; // 512 units of (8 px, 8 ch): 32 pixel groups x 16 channel groups
+                    const int p = (u & 31) * 8 + pl, c = (u >> 5) * 8 + cl;
+                    const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
+                    const int cx_ = min(ix, V.W - 1), cy_ = min(iy, V.H - 1);
+                    vals[j] = feats[M.pixel(cy_, cx_) + (int64_t)(c0 + c) * fs_c];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int u = (it0 + j) * 16 + rest;
+                    const int p = (u & 31) * 8 + pl, c = (u >> 5) * 8 + cl;
+                    lds[p * kChunk + c] = vals[j];
+                }
             }
         } else { // stage the 256 px x 128 ch slab: 32 float4 per pixel row
             constexpr int vpr = kChunk >> 2;
             constexpr int kIt = kTilePix * vpr / kThreads; // 8
             float4 vals[kIt];
+            int64_t offs[kIt]; // pixel offsets first (index maps make them loads; keep them out of the feature loads)
+#pragma unroll
+            for (int it = 0; it < kIt; ++it) {
+                const int idx = it * kThreads + threadIdx.x;
+                const int p = idx / vpr;
+                const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
+                // pixels past the image edge are never referenced by an entry: load a clamped (valid) address
+                // instead of branching, so the eight loads of a thread are all in flight before the first LDS write
+                offs[it] = M.pixel(min(iy, V.H - 1), min(ix, V.W - 1));
+            }
 #pragma unroll
             for (int it = 0; it < kIt; ++it) {
                 const int idx = it * kThreads + threadIdx.x;
                 const int p = idx / vpr, v = idx - p * vpr;
-                const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
-                // pixels past the image edge are never referenced by an entry: load a clamped (valid) address
-                // instead of branching, so the eight loads of a thread are all in flight before the first LDS write
-                const int cx_ = min(ix, V.W - 1), cy_ = min(iy, V.H - 1);
-                vals[it] =
-                    *reinterpret_cast<const float4 *>(feats + (int64_t)cy_ * fs_y + (int64_t)cx_ * fs_x + c0 + 4 * v);
+                vals[it] = *reinterpret_cast<const float4 *>(feats + offs[it] + c0 + 4 * v);
             }
 #pragma unroll
             for (int it = 0; it < kIt; ++it) {
@@ -337,14 +370,28 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
     }
     __syncthreads(); // every wave is done with this slab and work counter
     } // item loop
+    // A launch consumes its queue.  The last workgroup of the class to leave re-arms it, so the same weight store can be
+    // scattered again (second feature map, drop-in backward after a forward) without a host-side memset between the
+    // launches (a hipMemsetAsync here cost 0.35 ms per view in the two-stream pipeline).  Word 1 of the queue's line
+    // counts the leavers; every leaver made its last claim before it counts itself.
+    if (threadIdx.x == 0) {
+        const u32 left = atomicAdd(queue + 1, 1u);
+        if (left == gridDim.x / 8u - 1u) {
+            atomicExch(queue + 1, 0u);
+            atomicExch(queue, 0u);
+        }
+    }
 }
 
 } // namespace
 
-int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const float *feats, int64_t fs_y, int64_t fs_x,
-                        int64_t fs_c, int D, float scale_f, float scale_d, float *F, float *d, hipStream_t s)
+int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
+                        float scale_d, float *F, float *d, hipStream_t s)
 {
     const bool small = D <= 64;
+    // 16-B vector staging needs channel-contiguous, 16-B aligned pixel rows
+    const int vec_ok = M.fs_c == 1 && (M.fs_x % 4 == 0) && (M.fs_y % 4 == 0) &&
+                       ((reinterpret_cast<uintptr_t>(M.p) & 15) == 0);
     const int n_chunks = small ? 1 : D / kChunk;
     const int pitch = small ? ((D + 3) & ~3) : kChunk;
     const size_t lds_bytes = (size_t)kTilePix * pitch * sizeof(float) + 16; // slab + work counter + two item slots
@@ -378,12 +425,12 @@ int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const fl
     u32 *queues = W.shards + kShards * 16;
     if (small)
         hipLaunchKernelGGL(k_scatter_full<true>, dim3(grid), dim3(kThreads), lds_bytes, s, V, n_chunks, W.tile_offsets,
-                           W.hdr_count, W.headers, W.wpool, feats, fs_y, fs_x, fs_c, pitch, D, scale_f, scale_d, F, d,
-                           queues, ab ? atoi(ab) : 0);
+                           W.hdr_count, W.headers, W.wpool, M, vec_ok, pitch, D, scale_f, scale_d, F, d, queues,
+                           ab ? atoi(ab) : 0);
     else
         hipLaunchKernelGGL(k_scatter_full<false>, dim3(grid), dim3(kThreads), lds_bytes, s, V, n_chunks,
-                           W.tile_offsets, W.hdr_count, W.headers, W.wpool, feats, fs_y, fs_x, fs_c, pitch, D, scale_f,
-                           scale_d, F, d, queues, ab ? atoi(ab) : 0);
+                           W.tile_offsets, W.hdr_count, W.headers, W.wpool, M, vec_ok, pitch, D, scale_f, scale_d, F, d,
+                           queues, ab ? atoi(ab) : 0);
     return check_hip(hipGetLastError(), "scatter_full launch");
 }
 

@@ -16,6 +16,17 @@ from ._lib import Caps, GwbpError, Stats, check, make_view, ptr
 TILE = 16
 
 
+def nearest_index(n_in: int, n_out: int) -> torch.Tensor:
+    """Source index of every output index under torch.nn.functional.interpolate(mode="nearest"):
+    min(floor(dst * scale), n_in - 1) with scale = n_in / n_out, all in fp32 (ATen UpSample.h
+    nearest_neighbor_compute_source_index; the op the reference applies at backproject.py:244-248)."""
+    if n_in < 1 or n_out < 1:
+        raise ValueError("sizes must be positive")
+    scale = torch.tensor(float(n_in), dtype=torch.float32) / torch.tensor(float(n_out), dtype=torch.float32)
+    idx = torch.floor(torch.arange(n_out, dtype=torch.float32) * scale).to(torch.int64).clamp_(max=n_in - 1)
+    return idx.to(torch.int32)
+
+
 def _req(t: torch.Tensor, name: str, shape_tail=None) -> torch.Tensor:
     if not t.is_cuda:
         raise GwbpError(f"{name} must be a CUDA/HIP tensor (no CPU fallback exists for this path)")
@@ -35,6 +46,7 @@ class Engine:
         if self.device.type != "cuda":
             raise GwbpError("Engine needs a HIP device (there is no CPU path)")
         self.lib = _lib.lib()
+        self._maps: Dict[Tuple[int, int, int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
         self.n = int(n_gaussians)
         self.max_w, self.max_h = int(max_width), int(max_height)
         # Defaults: ~16 tiles per Gaussian and ~128 weights per pixel; both auto-grow on overflow.
@@ -107,8 +119,8 @@ class Engine:
         return alphas
 
     @staticmethod
-    def _feat_strides(feats: torch.Tensor, view) -> Tuple[int, int, int, int]:
-        if feats.dim() != 3 or feats.shape[0] != view.height or feats.shape[1] != view.width:
+    def _feat_strides(feats: torch.Tensor, view, lowres: bool = False) -> Tuple[int, int, int, int]:
+        if feats.dim() != 3 or (not lowres and (feats.shape[0] != view.height or feats.shape[1] != view.width)):
             raise GwbpError(f"feature map must be [H,W,D] = [{view.height},{view.width},D], got {tuple(feats.shape)}")
         if feats.dtype != torch.float32 or not feats.is_cuda:
             raise GwbpError("feature map must be a float32 HIP tensor")
@@ -117,12 +129,36 @@ class Engine:
             raise GwbpError("negative feature-map strides are not supported")
         return sy, sx, sc, feats.shape[2]
 
-    def scatter(self, view, feats, F, d, scale_f=1.0, scale_d=1.0):
-        sy, sx, sc, D = self._feat_strides(feats, view)
+    def scatter(self, view, feats, F, d, scale_f=1.0, scale_d=1.0, upsample: Optional[str] = None):
+        """F += scale_f * sum_p w feats[p], d += scale_d * sum_p w from the view's weight store.
+
+        upsample="nearest": feats is a LOW-RESOLUTION map [h,w,D]; the result equals scattering
+        F.interpolate(feats, size=(H,W), mode="nearest") (backproject.py:244-248) without building that map."""
+        if upsample is None:
+            sy, sx, sc, D = self._feat_strides(feats, view)
+            self._check_acc(F, d, D)
+            check(self.lib.gwbp_scatter(*self._args(), C.byref(view), ptr(feats), C.c_int64(sy), C.c_int64(sx),
+                                        C.c_int64(sc), D, C.c_float(scale_f), C.c_float(scale_d), ptr(F), ptr(d),
+                                        self._stream()), "gwbp_scatter")
+            return
+        if upsample != "nearest":
+            raise GwbpError(f"upsample must be None or 'nearest', got {upsample!r}")
+        sy, sx, sc, D = self._feat_strides(feats, view, lowres=True)
         self._check_acc(F, d, D)
-        check(self.lib.gwbp_scatter(*self._args(), C.byref(view), ptr(feats), C.c_int64(sy), C.c_int64(sx),
-                                    C.c_int64(sc), D, C.c_float(scale_f), C.c_float(scale_d), ptr(F), ptr(d),
-                                    self._stream()), "gwbp_scatter")
+        ymap, xmap = self.nearest_maps(feats.shape[0], feats.shape[1], view.height, view.width)
+        check(self.lib.gwbp_scatter_upsampled(*self._args(), C.byref(view), ptr(feats), C.c_int64(sy), C.c_int64(sx),
+                                              C.c_int64(sc), D, ptr(ymap), ptr(xmap), C.c_float(scale_f),
+                                              C.c_float(scale_d), ptr(F), ptr(d), self._stream()),
+              "gwbp_scatter_upsampled")
+
+    def nearest_maps(self, h: int, w: int, H: int, W: int):
+        """int32 device index maps of F.interpolate(mode="nearest"): (ymap[H], xmap[W]); cached per geometry."""
+        key = (h, w, H, W)
+        m = self._maps.get(key)
+        if m is None:
+            m = tuple(nearest_index(i, o).to(self.device) for i, o in ((h, H), (w, W)))
+            self._maps[key] = m
+        return m
 
     def render(self, view, colors):
         colors = _req(colors, "colors")

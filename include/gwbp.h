@@ -99,10 +99,20 @@ int gwbp_blend_weights(const gwbp_caps *caps, void *workspace, size_t workspace_
 /* What the reference obtains through backward(): F[g,:] += scale_f * sum_p w_g(p) * feats[p,:] and
  * d[g] += scale_d * sum_p w_g(p)   (backproject.py:127-131,145-150; scale = 1 for .sum(), 1/(H*W*D) and
  * 1/(H*W*3) for the dino .mean() variant, backproject.py:263,283).  feats is addressed as
- * feats[y*fs_y + x*fs_x + c*fs_c] (strides in floats; fs_c == 1 is the fast path).  d may be null. */
+ * feats[y*fs_y + x*fs_x + c*fs_c] (strides in floats; D % 128 == 0 or D <= 64 take the fast kernel; fs_c == 1 stages with 16-B loads).  d may be null. */
 int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                  const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c, int32_t D, float scale_f,
                  float scale_d, float *F, float *d, void *stream);
+
+/* gwbp_scatter over a LOW-RESOLUTION feature map that the reference would first upsample with
+ * F.interpolate(mode="nearest") (dino variant, backproject.py:244-248): pixel (y, x) of the view reads
+ * feats[ymap[y]*fs_y + xmap[x]*fs_x + c*fs_c].  ymap[view.height], xmap[view.width]: int32 device arrays (the host
+ * side builds them with PyTorch's nearest rule: min(floor(i * in/out), in-1) in fp32).  Same result as
+ * gwbp_scatter on the upsampled map, without ever materialising it. */
+int gwbp_scatter_upsampled(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
+                           const gwbp_view *view_host, const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c,
+                           int32_t D, const int32_t *ymap, const int32_t *xmap, float scale_f, float scale_d, float *F,
+                           float *d, void *stream);
 
 /* Forward render (what rasterization() returns): out[p,:] = sum_g w_g(p) * colors[g,:], out is [H,W,D]. */
 int gwbp_render(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,

@@ -382,3 +382,52 @@ def test_pipelined_driver_equals_serial_driver(dev):
         res.append((F.cpu().numpy(), dd.cpu().numpy(), st["n_pairs"]))
     assert res[0][2] == res[1][2]
     assert rel_row_err(res[0][0], res[1][0]) <= 1e-5 and np.abs(res[0][1] - res[1][1]).max() <= 1e-4 * res[1][1].max()
+
+
+@pytest.mark.parametrize("D", [384, 32, 130])
+def test_scatter_nearest_upsampled_lowres_map(orc, dev, D):
+    """dino variant (backproject.py:242-249): patch tokens [h,w,D] -> F.interpolate(nearest) -> scatter.  The HIP path
+    reads the low-resolution map through index maps; the oracle gets the materialised upsampled map."""
+    cfg, sc = scene_np("T1")
+    d, h = to_dev(sc, dev), npy(sc)
+    lh, lw = 13, 17
+    low = torch.randn(lh, lw, D, generator=torch.Generator().manual_seed(11))
+    up = torch.nn.functional.interpolate(low.permute(2, 0, 1)[None], size=(cfg.height, cfg.width), mode="nearest")[0]
+    up = up.permute(1, 2, 0)  # [H,W,D] view of a [D,H,W] tensor, exactly what the reference scatters
+    eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev)
+    view, _, _ = _front(eng, d, cfg, 0, want=False)
+    eng.blend_weights(view)
+    F1 = torch.zeros(cfg.n_gaussians, D, device=dev)
+    d1 = torch.zeros(cfg.n_gaussians, device=dev)
+    eng.scatter(view, low.to(dev), F1, d1, upsample="nearest")
+    F2 = torch.zeros_like(F1)
+    d2 = torch.zeros_like(d1)
+    eng.scatter(view, up.to(dev), F2, d2)  # channel-major strides: the element-wise staging path
+    Fr = np.zeros((cfg.n_gaussians, D), np.float64)
+    dr = np.zeros(cfg.n_gaussians, np.float64)
+    orc.backproject_view(h["means"], h["quats"], h["scales"], h["opac"], h["vms"][0], h["K"], cfg.width, cfg.height,
+                         np.ascontiguousarray(up.numpy()), Fr, dr)
+    assert rel_row_err(F1.cpu().numpy(), Fr) <= 1e-4
+    assert rel_row_err(F2.cpu().numpy(), Fr) <= 1e-4
+    assert torch.allclose(d1, d2, rtol=1e-5, atol=0)  # atomics: order of the per-tile partial sums differs
+    with pytest.raises(gsbp_amd.GwbpError):
+        eng.scatter(view, low.to(dev), F1, d1)  # a low-resolution map without upsample= is a shape error
+
+
+def test_create_feature_field_upsample_matches_materialised(dev):
+    cfg, sc = scene_np("T1")
+    d = to_dev(sc, dev)
+    D, lh, lw = 128, 9, 11
+    lows = [torch.randn(lh, lw, D, generator=torch.Generator().manual_seed(20 + v)).to(dev) for v in range(3)]
+
+    def full(v):
+        t = torch.nn.functional.interpolate(lows[v].permute(2, 0, 1)[None], size=(cfg.height, cfg.width), mode="nearest")
+        return t[0].permute(1, 2, 0)
+
+    args = (d["means"], d["quats"], d["scales"], d["opac"], d["vms"][:3], d["K"], cfg.width, cfg.height)
+    a = gsbp_amd.create_feature_field(*args, feature_fn=lambda v: lows[v], dim=D, reduction="mean", upsample="nearest")
+    b = gsbp_amd.create_feature_field(*args, feature_fn=full, dim=D, reduction="mean")
+    c = gsbp_amd.create_feature_field(*args, feature_fn=lambda v: lows[v], dim=D, reduction="mean", upsample="nearest",
+                                      pipeline=False)
+    assert rel_row_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
+    assert rel_row_err(c.cpu().numpy(), b.cpu().numpy()) <= 1e-5

@@ -91,3 +91,11 @@ def test_create_feature_field_cpu_injection_matches_direct(orc):
                                               lambda v: feats[v].numpy(), cfg.feat_dim, reduction=reduction)
         mine = orc.finalize(np.ascontiguousarray(acc["F"] * sf), np.ascontiguousarray(acc["d"] * sd))
         assert np.abs(mine - ref).max() < 1e-6
+
+
+def test_nearest_index_matches_torch_interpolate():
+    """The index maps gwbp_scatter_upsampled consumes must be F.interpolate(mode="nearest")'s (backproject.py:244-248)."""
+    for n_in, n_out in ((64, 1060), (64, 1600), (16, 224), (37, 300), (5, 5), (7, 3), (1, 9), (64, 1297), (3, 1000)):
+        src = torch.arange(n_in, dtype=torch.float32).reshape(1, 1, 1, n_in)
+        ref = torch.nn.functional.interpolate(src, size=(1, n_out), mode="nearest")[0, 0, 0].to(torch.int32)
+        assert torch.equal(gsbp_amd.nearest_index(n_in, n_out), ref), (n_in, n_out)
