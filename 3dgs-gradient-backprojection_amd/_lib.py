@@ -34,7 +34,7 @@ class View(C.Structure):
 class Caps(C.Structure):
     _fields_ = [("n_gaussians", C.c_int64), ("isect_cap", C.c_int64), ("pair_cap", C.c_int64),
                 ("max_width", C.c_int32), ("max_height", C.c_int32), ("scatter_workgroups", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("flags", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -44,6 +44,9 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+
+
+FLAG_TIGHT_BINNING = 1  # GWBP_FLAG_TIGHT_BINNING (include/gwbp.h)
 
 
 class GwbpError(RuntimeError):

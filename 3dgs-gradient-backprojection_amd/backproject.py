@@ -57,7 +57,8 @@ class ViewPipeline:
 
     def __init__(self, n_gaussians, width, height, device, engines=None):
         self.dev = torch.device(device)
-        self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev) for _ in range(2)]
+        self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev, tight_binning=True)
+                                                  for _ in range(2)]
         # Scatter grid under overlap: one persistent workgroup per CU is the measured optimum once the front stage is
         # light (C2: 4.24 ms/view at 256 vs 4.40 at 240); GWBP_PIPE_WGS overrides for tuning on other workloads.
         if "GWBP_PIPE_WGS" in os.environ:
@@ -145,9 +146,10 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     t0 = time.time()
     stats: Dict[str, int] = {}
     if view_fn is None:
-        eng = engine or Engine(n, width, height, device=dev)
+        eng = engine or Engine(n, width, height, device=dev, tight_binning=True)  # same F and d, shorter tile lists
         if pipeline and len(my_views) > 1:
             pipe = ViewPipeline(n, width, height, dev, engines=[eng, Engine(n, width, height, device=dev,
+                                                                            tight_binning=eng.tight_binning,
                                                                             isect_cap=eng.isect_cap,
                                                                             pair_cap=eng.pair_cap)])
             views = [eng.view(vm_host[v], K_host, width, height) for v in my_views]

@@ -43,6 +43,7 @@ int make_layout(const gwbp_caps *c, Layout *L)
     L->isect_cap = c->isect_cap;
     L->pair_cap = c->pair_cap;
     L->scatter_wgs = c->scatter_workgroups > 0 ? c->scatter_workgroups : 0;
+    L->flags = c->flags;
     const int tw = (c->max_width + kTile - 1) / kTile, th = (c->max_height + kTile - 1) / kTile;
     L->max_tiles = tw * th;
     L->n_scan_blocks = (int)((L->n + kScanBlock - 1) / kScanBlock);

@@ -71,7 +71,7 @@ struct Layout {
     size_t counters, shards, g2d, rect, touched, blocksums, dkeys[2], dvals[2], keys[2], vals[2], hist, digit_total, tile_offsets, tile_order, hdr_count,
         headers, wpool;
     int64_t n, isect_cap, pair_cap;
-    int max_tiles, n_scan_blocks, n_sort_blocks, scatter_wgs;
+    int max_tiles, n_scan_blocks, n_sort_blocks, scatter_wgs, flags;
 };
 
 struct Ws {

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(kScanBlock) void k_project(
     const float *__restrict__ scales, const float *__restrict__ opac, G2D *__restrict__ g2d,
     uint2 *__restrict__ rect, u32 *__restrict__ touched, u32 *__restrict__ dkeys, u32 *__restrict__ dvals,
     Counters *__restrict__ ctr, int32_t *__restrict__ o_radii, float *__restrict__ o_means2d, float *__restrict__ o_depths,
-    float *__restrict__ o_conics)
+    float *__restrict__ o_conics, int tight)
 {
     const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
     u32 ntiles = 0;
@@ -111,7 +111,31 @@ __global__ __launch_bounds__(kScanBlock) void k_project(
                     const float fminy = __builtin_fminf(__builtin_fmaxf(__builtin_floorf(tcy - tr), 0.f), thf);
                     const float fmaxx = __builtin_fminf(__builtin_fmaxf(__builtin_ceilf(tcx + tr), 0.f), twf);
                     const float fmaxy = __builtin_fminf(__builtin_fmaxf(__builtin_ceilf(tcy + tr), 0.f), thf);
-                    const u32 x0 = (u32)fminx, y0 = (u32)fminy, x1 = (u32)fmaxx, y1 = (u32)fmaxy;
+                    u32 x0 = (u32)fminx, y0 = (u32)fminy, x1 = (u32)fmaxx, y1 = (u32)fmaxy;
+                    if (tight) {
+                        // GWBP_FLAG_TIGHT_BINNING: alpha = o exp(-sigma) >= 1/255 needs sigma <= L = ln(255 o), and
+                        // sigma >= dx^2 / (2 Sxx) for every dy (Sxx = c00, the 2-D covariance), so a pixel centre farther
+                        // than sqrt(2 L c00) from the mean in x (c11 in y) cannot contribute.  Same bound, same 5 % + 1 px
+                        // margin and same 1e-3 slack on L as the strip mask of k_blend (which the parity tests pin).
+                        const float L = __logf(255.0f * opac[i]) + 1e-3f;
+                        if (!(L > 0.f)) {
+                            x1 = x0, y1 = y0; // o <= 1/255: never reaches alpha >= 1/255
+                        } else {
+                            const float ex = 1.05f * __builtin_sqrtf(2.0f * L * c00) + 1.0f;
+                            const float ey = 1.05f * __builtin_sqrtf(2.0f * L * c11) + 1.0f;
+                            if (ex == ex && ey == ey) { // degenerate values: keep the 3-sigma square
+                                // pixel centres are at integer + 0.5: tiles whose centres fall inside [m - e, m + e]
+                                const float lx = __builtin_floorf((u - ex - 0.5f) / ts), hx = __builtin_floorf((u + ex - 0.5f) / ts) + 1.0f;
+                                const float ly = __builtin_floorf((v - ey - 0.5f) / ts), hy = __builtin_floorf((v + ey - 0.5f) / ts) + 1.0f;
+                                x0 = max(x0, (u32)__builtin_fmaxf(lx, 0.f)), y0 = max(y0, (u32)__builtin_fmaxf(ly, 0.f));
+                                x1 = min(x1, (u32)__builtin_fmaxf(hx, 0.f)), y1 = min(y1, (u32)__builtin_fmaxf(hy, 0.f));
+                                if (x1 < x0)
+                                    x1 = x0;
+                                if (y1 < y0)
+                                    y1 = y0;
+                            }
+                        }
+                    }
                     g.mx = u, g.my = v, g.opac = opac[i], g.depth = z;
                     g.ca = c11 * inv_det, g.cb = -c01 * inv_det, g.cc = c00 * inv_det;
                     g.radius = (int)radf;
@@ -292,7 +316,8 @@ int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *
     if (L.n == 0)
         return GWBP_OK;
     hipLaunchKernelGGL(k_project, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, V, means, quats, scales, opac,
-                       W.g2d, W.rect, W.touched, W.dkeys[0], W.dvals[0], W.counters, radii, means2d, depths, conics);
+                       W.g2d, W.rect, W.touched, W.dkeys[0], W.dvals[0], W.counters, radii, means2d, depths, conics,
+                       L.flags & GWBP_FLAG_TIGHT_BINNING);
     return check_hip(hipGetLastError(), "project launch");
 }
 

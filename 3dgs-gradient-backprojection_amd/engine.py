@@ -41,7 +41,8 @@ class Engine:
     """Workspace sized for (N Gaussians, max WxH, isect_cap, pair_cap) on one device."""
 
     def __init__(self, n_gaussians: int, max_width: int, max_height: int, device=None,
-                 isect_cap: Optional[int] = None, pair_cap: Optional[int] = None, scatter_workgroups: int = 0):
+                 isect_cap: Optional[int] = None, pair_cap: Optional[int] = None, scatter_workgroups: int = 0,
+                 tight_binning: bool = False):
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
             raise GwbpError("Engine needs a HIP device (there is no CPU path)")
@@ -53,10 +54,14 @@ class Engine:
         self.isect_cap = int(isect_cap or max(1 << 18, 16 * self.n))
         self.pair_cap = int(pair_cap or max(1 << 20, 128 * self.max_w * self.max_h))
         self.scatter_workgroups = int(scatter_workgroups)  # 0 = one persistent scatter workgroup per CU
+        # tight_binning: GWBP_FLAG_TIGHT_BINNING -- same F, d, weights and renders, shorter tile lists; off by default
+        # because meta["isect_ids"] of the drop-in operator must show gsplat's 3-sigma binning
+        self.tight_binning = bool(tight_binning)
         self._alloc()
 
     def _alloc(self):
-        self.caps = Caps(self.n, self.isect_cap, self.pair_cap, self.max_w, self.max_h, self.scatter_workgroups, 0)
+        self.caps = Caps(self.n, self.isect_cap, self.pair_cap, self.max_w, self.max_h, self.scatter_workgroups,
+                         _lib.FLAG_TIGHT_BINNING if self.tight_binning else 0)
         nbytes = C.c_size_t(0)
         check(self.lib.gwbp_workspace_size(C.byref(self.caps), C.byref(nbytes)), "gwbp_workspace_size")
         self.ws_bytes = int(nbytes.value)

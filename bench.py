@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=1)
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
+    ap.add_argument("--exact-binning", action="store_true",
+                    help="gsplat's 3-sigma tile binning instead of GWBP_FLAG_TIGHT_BINNING (same F and d either way)")
     ap.add_argument("--serial", action="store_true", help="one stream, no overlap of front(v+1) with scatter(v)")
     args = ap.parse_args()
 
@@ -74,7 +76,8 @@ def main():
 
     # feature-map pool, generated on device (seeded), L2-normalised over channels like backproject.py:109
     pool = [syn.make_feature_map(cfg, 1000 * rank + i, device=dev) for i in range(args.pool)]
-    eng = gsbp_amd.Engine(N, W, H, device=dev)
+    tight = not args.exact_binning
+    eng = gsbp_amd.Engine(N, W, H, device=dev, tight_binning=tight)
     F = torch.zeros(N, D, device=dev)
     d = torch.zeros(N, device=dev)
     my_views = [rank + world * i for i in range(args.steps + args.warmup)]
@@ -91,7 +94,7 @@ def main():
     if args.serial:
         pipe, accum = None, torch.zeros(32, dtype=torch.uint8, device=dev)
     else:
-        eng2 = gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap)
+        eng2 = gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap, tight_binning=tight)
         pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng, eng2])
         accum = pipe.accum
 
@@ -197,6 +200,7 @@ def main():
                                    + f", {args.steps} views/GPU, view-sharded over {world} GPU(s), one all-reduce",
                        "views_per_sec": world * args.steps / elapsed, "pairs_per_view": pairs_view,
                        "n_visible_per_view": n_vis, "n_isect_per_view": n_isect, "n_headers_per_view": n_hdr,
+                       "binning": "alpha-ellipse bounding box (GWBP_FLAG_TIGHT_BINNING)" if tight else "gsplat 3-sigma square",
                        "overflow": overflow,
                        "schedule": "serial" if args.serial else "front(v+1) overlapped with scatter(v) on two streams",
                        "stage_ms": {"front(project+sort+blend, side stream, overlapped)": t_front,

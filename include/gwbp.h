@@ -56,8 +56,15 @@ typedef struct gwbp_caps {
     /* Tuning: number of persistent scatter workgroups (rounded up to a multiple of 8); 0 = one per CU (default and
      * measured optimum on MI355X, also when the next view's front stages overlap on a second stream). */
     int32_t scatter_workgroups;
-    int32_t reserved;
+    /* GWBP_FLAG_* bits; 0 = gsplat's exact tile binning (3-sigma square, what meta["isect_ids"] must show). */
+    int32_t flags;
 } gwbp_caps;
+
+/* Bin every Gaussian only into the tiles that the bounding box of its alpha >= 1/255 ellipse touches (clipped to the
+ * 3-sigma square): low-opacity and elongated Gaussians enter fewer tile lists.  A dropped (Gaussian, tile) pair has no
+ * pixel with alpha >= 1/255 (5 % + 1 px margin), so F, d, the weight store and every render are unchanged bit for bit;
+ * only n_isect and the sorted intersection lists shrink.  Used by the fused back-projection path. */
+#define GWBP_FLAG_TIGHT_BINNING 1
 
 /* Device-resident per-view counters, readable after the stream has drained (gwbp_read_stats). */
 typedef struct gwbp_stats {

@@ -431,3 +431,27 @@ def test_create_feature_field_upsample_matches_materialised(dev):
                                       pipeline=False)
     assert rel_row_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
     assert rel_row_err(c.cpu().numpy(), b.cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["T0", "T1", "C1"])
+def test_tight_binning_changes_only_the_lists(name, dev):
+    """GWBP_FLAG_TIGHT_BINNING drops (Gaussian, tile) pairs that cannot contribute: the weight store -- every
+    (gaussian, pixel, w) triple -- and therefore F and d must be identical to the exact binning, bit for bit."""
+    cfg, sc = scene_np(name)
+    d = to_dev(sc, dev)
+    exact = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev)
+    tight = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, tight_binning=True)
+    for v in range(min(cfg.n_views, 2)):
+        out = []
+        for eng in (exact, tight):
+            view, _, _ = _front(eng, d, cfg, v, want=False)
+            alphas = eng.blend_weights(view, want_alphas=True)
+            st = eng.stats()
+            gid, pix, w = eng.dump_pairs(view)
+            key, ws = sort_pairs(gid.cpu().numpy(), pix.cpu().numpy(), w.cpu().numpy())
+            out.append((st, key, ws, alphas.cpu().numpy()))
+        (s0, k0, w0, a0), (s1, k1, w1, a1) = out
+        assert s1["n_pairs"] == s0["n_pairs"] and s1["n_visible"] == s0["n_visible"] and s1["n_headers"] == s0["n_headers"]
+        assert s1["n_isect"] < s0["n_isect"]
+        assert np.array_equal(k0, k1) and np.array_equal(w0.view(np.uint32), w1.view(np.uint32))
+        assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
