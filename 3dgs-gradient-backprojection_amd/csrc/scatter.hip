@@ -196,69 +196,6 @@ __global__ __launch_bounds__(kScatterThreads) void k_scatter(
     }
 }
 
-// Forward render: out[p, c] = sum_g w_g(p) * colors[g, c]  (what rasterization() returns as render_colors).
-// workgroup = (tile, 128-channel chunk), 4 waves; wave q owns tile rows 4q..4q+3 (its quarter of every mask), so
-// the LDS accumulators need no atomics and every pixel is summed front to back: deterministic.
-__global__ __launch_bounds__(256) void k_render(ViewDev V, int n_chunks, int pitch,
-                                                const u32 *__restrict__ tile_offsets,
-                                                const u32 *__restrict__ hdr_count,
-                                                const Header *__restrict__ headers,
-                                                const WPair *__restrict__ wpool, const float *__restrict__ colors,
-                                                int D, float *__restrict__ out)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[]; // [256][pitch]
-    const u32 b = blockIdx.x;
-    const u32 x = b & 7u, sidx = b >> 3;
-    const int chunk = (int)(sidx % (u32)n_chunks);
-    const int tile = (int)((sidx / (u32)n_chunks) * 8u + x);
-    if (tile >= V.tile_w * V.tile_h)
-        return;
-    const int tx = tile % V.tile_w, ty = tile / V.tile_w;
-    const int c0 = chunk * kChunk;
-    const int cw = min(pitch, D - c0);
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    for (int idx = threadIdx.x; idx < kTilePix * pitch; idx += 256)
-        lds[idx] = 0.f;
-    __syncthreads();
-    const u32 nh = hdr_count[tile];
-    const Header *hbase = headers + tile_offsets[tile];
-    const bool c_on0 = 2 * lane < cw, c_on1 = 2 * lane + 1 < cw;
-    float *qrow = lds + q * 64 * pitch + 2 * lane;
-    for (u32 h = 0; h < nh; ++h) {
-        const Header *hp = hbase + h;
-        u64 m = uniform64(hp->mask[q]);
-        if (m == 0ull)
-            continue;
-        const u32 gid = uniform(hp->gid);
-        const u32 cnt = (u32)__popcll(m);
-        const u32 woff = uniform(hp->woff[q]);
-        const float wv = ((u32)lane < cnt) ? wpool[woff + lane].w : 0.f;
-        const float *cg = colors + (int64_t)gid * D + c0 + 2 * lane;
-        const float col0 = c_on0 ? cg[0] : 0.f, col1 = c_on1 ? cg[1] : 0.f;
-        u32 k = 0;
-        while (m) {
-            const int p = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const float w = readlane_f(wv, k);
-            ++k;
-            if (2 * lane < pitch) {
-                float2 *dst = reinterpret_cast<float2 *>(qrow + p * pitch);
-                float2 a = *dst;
-                a.x = __builtin_fmaf(w, col0, a.x);
-                a.y = __builtin_fmaf(w, col1, a.y);
-                *dst = a;
-            }
-        }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < kTilePix * pitch; idx += 256) {
-        const int p = idx / pitch, c = idx - p * pitch;
-        const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
-        if (ix < V.W && iy < V.H && c < cw)
-            out[((int64_t)iy * V.W + ix) * D + c0 + c] = lds[idx];
-    }
-}
-
 // backproject.py:63,166-169 -- one wave per Gaussian row.
 __global__ __launch_bounds__(256) void k_finalize(int64_t N, int D, const float *__restrict__ F,
                                                   const float *__restrict__ d, float *__restrict__ out)
@@ -318,11 +255,6 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap
                            "scatter LDS attribute");
         if (rc)
             return rc;
-        rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64),
-                       "render LDS attribute");
-        if (rc)
-            return rc;
         attr_done = true;
     }
     // fast paths (scatter_full.hip): D % 128 == 0 or D <= 64, any strides
@@ -333,25 +265,6 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap
                            n_tiles_pad, n_chunks, pitch, W.tile_offsets, W.hdr_count, W.headers, W.wpool, M, D, scale_f,
                            scale_d, F, d);
     return check_hip(hipGetLastError(), "scatter launch");
-}
-
-int launch_render(const Layout &L, const Ws &W, const ViewDev &V, const float *colors, int D, float *out,
-                  hipStream_t s)
-{
-    (void)L;
-    const int n_tiles = V.tile_w * V.tile_h;
-    const int n_tiles_pad = (n_tiles + 7) & ~7;
-    const int n_chunks = (D + kChunk - 1) / kChunk;
-    const int pitch = chunk_pitch(D);
-    const size_t lds_bytes = (size_t)kTilePix * pitch * sizeof(float);
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64),
-                       "render LDS attribute");
-    if (rc)
-        return rc;
-    hipLaunchKernelGGL(k_render, dim3(n_tiles_pad * n_chunks), dim3(256), lds_bytes, s, V, n_chunks, pitch,
-                       W.tile_offsets, W.hdr_count, W.headers, W.wpool, colors, D, out);
-    return check_hip(hipGetLastError(), "render launch");
 }
 
 int launch_finalize(int64_t N, int D, const float *F, const float *d, float *out, hipStream_t s)
