@@ -120,18 +120,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u32 *__res
     }
     __syncthreads();
 
-    u32 key[kItemsPerThread];
-    u32 val[kItemsPerThread];
-    u32 rank[kItemsPerThread];
+    // Only {rank, digit} of an item survives the two barriers (one packed dword); keys and values are re-read for the
+    // scatter (the block's 16 KB are L2-resident).  Holding key[16] + val[16] + rank[16] put the kernel at 106 VGPRs: one
+    // block per CU beside the persistent scatter workgroup, where each pass then took 200-260 us instead of 30.
+    u32 rd[kItemsPerThread]; // rank | digit << 16   (rank < 4096)
     const u32 seg = base + wave * (u32)kWaveItems;
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int it = 0; it < kItemsPerThread; ++it) {
         const u32 idx = seg + it * 64 + lane;
         const bool valid = idx < n;
-        key[it] = valid ? keys_in[idx] : ~0u;
-        val[it] = valid ? vals_in[idx] : 0u;
-        const u32 dg = (u32)(key[it] >> shift) & 0xFFu;
+        const u32 key = valid ? keys_in[idx] : ~0u;
+        const u32 dg = (u32)(key >> shift) & 0xFFu;
         u64 peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u32 *__res
             s_cnt[wave][dg] = old + (u32)__popcll(peers);
         }
         old = __shfl(old, leader, 64);
-        rank[it] = old + (u32)__popcll(peers & lt);
+        rd[it] = (old + (u32)__popcll(peers & lt)) | (dg << 16);
     }
     __syncthreads();
     { // thread = digit: turn per-wave counts into global bases
@@ -164,10 +164,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u32 *__res
     for (int it = 0; it < kItemsPerThread; ++it) {
         const u32 idx = seg + it * 64 + lane;
         if (idx < n) {
-            const u32 dg = (u32)(key[it] >> shift) & 0xFFu;
-            const u32 pos = s_cnt[wave][dg] + rank[it];
-            keys_out[pos] = key[it];
-            vals_out[pos] = val[it];
+            const u32 pos = s_cnt[wave][rd[it] >> 16] + (rd[it] & 0xFFFFu);
+            keys_out[pos] = keys_in[idx];
+            vals_out[pos] = vals_in[idx];
         }
     }
 }
