@@ -15,7 +15,7 @@ for f in glob.glob(f"{src}/pmc_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         key = (r["Dispatch_Id"], r["Counter_Name"])
         per_dispatch[key] += float(r["Counter_Value"])
-        names[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+        names[r["Dispatch_Id"]] = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     for (disp, cname), val in per_dispatch.items():
         raw[names[disp]][cname].append(val)
 avg = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in raw.items() if k.startswith("gwbp::")}
