@@ -35,6 +35,26 @@ def reduce_partials(F: torch.Tensor, d: torch.Tensor) -> None:
         dist.all_reduce(d, op=dist.ReduceOp.SUM)
 
 
+def reduce_partials_sharded(F: torch.Tensor, d: torch.Tensor):
+    """The exchange step as a reduce-scatter: rank r receives rows [row0, row0 + n_r) of the summed F (and d), which is
+    all the row-local finalise needs (backproject.py:166-169) -- half the xGMI traffic of the all-reduce; an all-gather
+    is only needed if one rank must hold the whole field.  Returns (F_rows, d_rows, row0).
+    Falls back to all-reduce + slice when N does not divide evenly or the backend has no reduce-scatter (gloo)."""
+    dist, rank, world = _dist()
+    n = F.shape[0]
+    if world == 1:
+        return F, d, 0
+    per = -(-n // world)
+    row0, row1 = min(rank * per, n), min((rank + 1) * per, n)
+    dist.all_reduce(d, op=dist.ReduceOp.SUM)  # 4 B per Gaussian
+    if n % world == 0 and dist.get_backend() != "gloo":
+        out = torch.empty(per, F.shape[1], device=F.device, dtype=F.dtype)
+        dist.reduce_scatter_tensor(out, F, op=dist.ReduceOp.SUM)
+        return out, d[row0:row1], row0
+    dist.all_reduce(F, op=dist.ReduceOp.SUM)
+    return F[row0:row1], d[row0:row1], row0
+
+
 def finalize_reference(F: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
     """backproject.py:63,166-169 in plain torch (host logic used by the CPU/gloo tests; the GPU path calls
     Engine.finalize -> gwbp_finalize)."""
@@ -65,7 +85,10 @@ class ViewPipeline:
             for e in self.eng:
                 e.scatter_workgroups = int(os.environ["GWBP_PIPE_WGS"])
                 e.caps.scatter_workgroups = e.scatter_workgroups
-        self.side = torch.cuda.Stream(device=self.dev)
+        # High priority = a hardware queue of its own.  With default priority the side stream can land on the main
+        # stream's hardware queue (it does once RCCL has created its streams: GPU_MAX_HW_QUEUES is 4), the two streams
+        # then run strictly one after the other and the step is front + scatter (5.06 instead of 4.27 ms/view at C2).
+        self.side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("GWBP_SIDE_PRIO", "-1")))
         self.ev_front = [torch.cuda.Event() for _ in range(2)]
         self.ev_done = [torch.cuda.Event() for _ in range(2)]
         self.accum = torch.zeros(32, dtype=torch.uint8, device=self.dev)

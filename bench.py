@@ -21,6 +21,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the two-stream view pipeline needs its streams on different hardware queues (default 4; RCCL takes some): see
+# ViewPipeline.  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
@@ -146,6 +149,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if use_dist:  # first use of each collective (communicator channels, staging buffers) stays outside the timed region
+        wf = torch.zeros(world * 8, D, device=dev)
+        gsbp_amd.reduce_partials_sharded(wf, torch.zeros(world * 8, device=dev))
     barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, n_total):
@@ -153,7 +159,9 @@ def main():
             front(i + 1)
         scatter(i)
     if use_dist:
-        gsbp_amd.reduce_partials(F, d)
+        # the path's one exchange step, inside the timed region: reduce-scatter of F (rank r keeps the rows it would
+        # finalise), all-reduce of d
+        F_rows, d_rows, row0 = gsbp_amd.reduce_partials_sharded(F, d)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -197,7 +205,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg.name}: {N} Gaussians, {W}x{H} views, D={D_in}"
                                    + (f"->{D} (encoder)" if encoder is not None else "")
-                                   + f", {args.steps} views/GPU, view-sharded over {world} GPU(s), one all-reduce",
+                                   + f", {args.steps} views/GPU, view-sharded over {world} GPU(s), one reduce-scatter of F + all-reduce of d",
                        "views_per_sec": world * args.steps / elapsed, "pairs_per_view": pairs_view,
                        "n_visible_per_view": n_vis, "n_isect_per_view": n_isect, "n_headers_per_view": n_hdr,
                        "binning": "alpha-ellipse bounding box (GWBP_FLAG_TIGHT_BINNING)" if tight else "gsplat 3-sigma square",

@@ -38,7 +38,12 @@ def _worker(rank, world, port, q):
     gsbp_amd.create_feature_field(means, quats, scales, opac, vms, K, cfg.width, cfg.height,
                                   lambda v: syn.make_feature_map(cfg, v), cfg.feat_dim, view_fn=view_fn)
     assert seen == syn.view_shard(cfg.n_views, rank, world)
+    # the sharded form of the exchange (what bench.py times): rank r gets its block of rows of the summed F and d
+    F_rows, d_rows, row0 = gsbp_amd.reduce_partials_sharded(F.clone(), d.clone())
     gsbp_amd.reduce_partials(F, d)  # the single exchange step
+    assert torch.equal(F_rows, F[row0:row0 + F_rows.shape[0]]) and torch.equal(d_rows, d[row0:row0 + d_rows.shape[0]])
+    per = -(-cfg.n_gaussians // world)
+    assert row0 == rank * per and F_rows.shape[0] == min(per, cfg.n_gaussians - row0)
     out = gsbp_amd.finalize_reference(F, d)
     if rank == 0:
         q.put((out.numpy(), F.numpy(), d.numpy()))
