@@ -100,3 +100,29 @@ def test_random_scene_matches_oracle(case, orc, dev):
     if ok.any():
         assert rel_row_err(out[ok], ref[ok]) <= 1e-4
     assert np.array_equal(out[dr == 0], np.zeros_like(out[dr == 0]))
+
+
+@pytest.mark.parametrize("wgs", [8, 24, 1000])
+def test_scatter_grid_size_does_not_change_the_result(wgs, orc, dev):
+    """caps.scatter_workgroups: any persistent grid (fewer workgroups than XCD classes x tiles, more than CUs) must
+    drain the per-class queues completely and re-arm them (two scatters on one weight store)."""
+    seed, n, W, H, D, s0 = 42, 3000, 200, 150, 128, 0.03
+    means, quats, scales, opac = _scene(seed, n, s0)
+    vm, K = _camera(seed, W, H)
+    feats = torch.randn(H, W, D, generator=torch.Generator().manual_seed(7))
+    eng = gsbp_amd.Engine(n, W, H, device=dev, scatter_workgroups=wgs)
+    view = eng.view(vm, K, W, H)
+    g_dev = [t.to(dev) for t in (means, quats, scales, opac)]
+    eng.project(view, *g_dev)
+    eng.bin_sort(view)
+    eng.blend_weights(view)
+    F = torch.zeros(n, D, device=dev)
+    d = torch.zeros(n, device=dev)
+    eng.scatter(view, feats.to(dev), F, d)
+    eng.scatter(view, feats.to(dev), F, d)  # same store again: the queues must have re-armed themselves
+    Fr = np.zeros((n, D), np.float64)
+    dr = np.zeros(n, np.float64)
+    orc.backproject_view(*[t.numpy() for t in (means, quats, scales, opac)], vm.numpy(), K.numpy(), W, H,
+                         feats.numpy(), Fr, dr)
+    assert rel_row_err(F.cpu().numpy(), 2.0 * Fr) <= 1e-4
+    assert rel_row_err(d.cpu().numpy()[:, None], 2.0 * dr[:, None]) <= 1e-4
