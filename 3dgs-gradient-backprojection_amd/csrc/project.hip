@@ -203,18 +203,21 @@ __global__ __launch_bounds__(kScanBlock) void k_sorted_blocksums(int64_t N, cons
     }
 }
 
-// Exclusive scan of the per-block totals (single workgroup, 1024 threads, carry loop); publishes n_isect.
-__global__ __launch_bounds__(1024) void k_scan_blocksums(int nblk, u32 *__restrict__ blocksums,
-                                                         Counters *__restrict__ ctr, u32 isect_cap)
+// Exclusive scan of the per-block totals (single workgroup, carry loop); publishes n_isect.  256 threads, not 1024: a
+// 16-wave workgroup needs four free wave slots on every SIMD of ONE CU at the same moment, and beside the persistent
+// scatter workgroups the dispatcher can wait milliseconds for that (2.9 ms measured with a 12-wave scatter kernel).
+constexpr int kSumThreads = 256;
+__global__ __launch_bounds__(kSumThreads) void k_scan_blocksums(int nblk, u32 *__restrict__ blocksums,
+                                                                Counters *__restrict__ ctr, u32 isect_cap)
 {
-    __shared__ u32 s_wave[16];
+    __shared__ u32 s_wave[kSumThreads / 64];
     __shared__ u32 s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0)
         s_carry = 0;
     __syncthreads();
-    u64 total = 0; // tracked by thread 0 in 64 bits to detect wrap
-    for (int base = 0; base < nblk; base += 1024) {
+    u64 total = 0; // tracked by the last thread in 64 bits to detect wrap
+    for (int base = 0; base < nblk; base += kSumThreads) {
         const int i = base + threadIdx.x;
         const u32 v = (i < nblk) ? blocksums[i] : 0u;
         u32 incl = v;
@@ -234,13 +237,13 @@ __global__ __launch_bounds__(1024) void k_scan_blocksums(int nblk, u32 *__restri
         if (i < nblk)
             blocksums[i] = carry + woff + incl - v;
         __syncthreads();
-        if (threadIdx.x == 1023) {
+        if (threadIdx.x == kSumThreads - 1) {
             total += (u64)woff + incl;
             s_carry = carry + woff + incl;
         }
         __syncthreads();
     }
-    if (threadIdx.x == 1023) {
+    if (threadIdx.x == kSumThreads - 1) {
         if (total > (u64)isect_cap) {
             atomicOr(&ctr->overflow, 1u);
             ctr->n_isect = 0; // downstream stages see an empty view; caller must retry with larger caps
@@ -297,7 +300,7 @@ int launch_emit(const Layout &L, const Ws &W, const ViewDev &V, const u32 *order
 {
     hipLaunchKernelGGL(k_sorted_blocksums, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, order, W.touched,
                        W.blocksums);
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, s, L.n_scan_blocks, W.blocksums, W.counters,
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(kSumThreads), 0, s, L.n_scan_blocks, W.blocksums, W.counters,
                        (u32)L.isect_cap);
     hipLaunchKernelGGL(k_emit, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, V.tile_w, order, W.rect, W.touched,
                        W.blocksums, W.counters, W.keys[0], W.vals[0]);

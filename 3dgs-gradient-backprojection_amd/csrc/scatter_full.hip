@@ -409,7 +409,7 @@ int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const Fe
             return rc;
         attr_done = true;
     }
-    const char *ab = getenv("GWBP_ABLATE"); // profiling ablation only (results are invalid when set)
+    static const char *ab = getenv("GWBP_ABLATE"); // profiling ablation only, read once (results are invalid when set)
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;

@@ -212,21 +212,30 @@ __global__ void k_export_sorted(const u32 *__restrict__ keys, const u32 *__restr
 // Tiles ordered by descending list length (counting sort into 1024 buckets of 4 entries, one workgroup).  k_blend runs
 // one wave per tile, so its critical path is the longest list: starting those waves first keeps them off the tail,
 // which matters most when the kernel shares the CUs with the persistent scatter workgroups (ViewPipeline).
-__global__ __launch_bounds__(1024) void k_tile_order(const u32 *__restrict__ tile_offsets, int n_tiles,
-                                                     u32 *__restrict__ order)
+// 256 threads x 4 buckets each (a 1024-thread workgroup is hard to place beside the scatter workgroups, see
+// k_scan_blocksums).
+constexpr int kOrderThreads = 256;
+__global__ __launch_bounds__(kOrderThreads) void k_tile_order(const u32 *__restrict__ tile_offsets, int n_tiles,
+                                                              u32 *__restrict__ order)
 {
     __shared__ u32 s_cnt[1024];
-    s_cnt[threadIdx.x] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        s_cnt[4 * threadIdx.x + j] = 0;
     __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += 1024) {
+    for (int t = threadIdx.x; t < n_tiles; t += kOrderThreads) {
         const u32 len = tile_offsets[t + 1] - tile_offsets[t];
         atomicAdd(&s_cnt[1023u - min(len >> 2, 1023u)], 1u); // bucket 0 = longest lists
     }
     __syncthreads();
-    // exclusive scan of the 1024 bucket counts
+    // exclusive scan of the 1024 bucket counts: thread t owns buckets 4t .. 4t+3
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ u32 s_w[16];
-    const u32 v = s_cnt[threadIdx.x];
+    __shared__ u32 s_w[kOrderThreads / 64];
+    u32 c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        c[j] = s_cnt[4 * threadIdx.x + j];
+    const u32 v = c[0] + c[1] + c[2] + c[3];
     u32 incl = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -237,13 +246,16 @@ __global__ __launch_bounds__(1024) void k_tile_order(const u32 *__restrict__ til
     if (lane == 63)
         s_w[wave] = incl;
     __syncthreads();
-    u32 woff = 0;
+    u32 run = incl - v;
     for (int w = 0; w < wave; ++w)
-        woff += s_w[w];
+        run += s_w[w];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s_cnt[4 * threadIdx.x + j] = run;
+        run += c[j];
+    }
     __syncthreads();
-    s_cnt[threadIdx.x] = woff + incl - v;
-    __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += 1024) {
+    for (int t = threadIdx.x; t < n_tiles; t += kOrderThreads) {
         const u32 len = tile_offsets[t + 1] - tile_offsets[t];
         order[atomicAdd(&s_cnt[1023u - min(len >> 2, 1023u)], 1u)] = (u32)t;
     }
@@ -289,7 +301,7 @@ int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *ise
     const int ob = (int)((L.isect_cap + 255) / 256);
     hipLaunchKernelGGL(k_tile_offsets, dim3(ob > 0 ? ob : 1), dim3(256), 0, s, W.keys[fin], W.counters, n_tiles,
                        W.tile_offsets);
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, W.tile_offsets, n_tiles, W.tile_order);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kOrderThreads), 0, s, W.tile_offsets, n_tiles, W.tile_order);
     if (isect_ids || flatten_ids)
         hipLaunchKernelGGL(k_export_sorted, dim3(1024), dim3(256), 0, s, W.keys[fin], W.vals[fin], W.g2d, W.counters,
                            L.isect_cap, isect_ids, flatten_ids);
