@@ -234,6 +234,13 @@ def main():
         dist.destroy_process_group()
     if line is not None:
         print(line, flush=True)  # the ONE JSON line, after any RCCL teardown chatter
+    if use_dist:
+        # RCCL prints its version banner from a library destructor when NCCL_DEBUG=VERSION is set (it is on the GPU
+        # boxes), i.e. AFTER this point and on stdout.  Leave without running destructors so that the JSON line stays
+        # the last line of stdout; everything is flushed and the process group is already destroyed.
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder, n_views):
