@@ -75,7 +75,7 @@ class ViewPipeline:
     (workspace reuse).  Nothing synchronises the host.
     """
 
-    def __init__(self, n_gaussians, width, height, device, engines=None):
+    def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None):
         self.dev = torch.device(device)
         self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev, tight_binning=True)
                                                   for _ in range(2)]
@@ -88,6 +88,8 @@ class ViewPipeline:
         # High priority = a hardware queue of its own.  With default priority the side stream can land on the main
         # stream's hardware queue (it does once RCCL has created its streams: GPU_MAX_HW_QUEUES is 4), the two streams
         # then run strictly one after the other and the step is front + scatter (5.06 instead of 4.27 ms/view at C2).
+        self.scatter_dim = scatter_dim
+        self.choose_scatter_kernel(None, None)
         self.side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("GWBP_SIDE_PRIO", "-1")))
         self.ev_front = [torch.cuda.Event() for _ in range(2)]
         self.ev_done = [torch.cuda.Event() for _ in range(2)]
@@ -95,6 +97,23 @@ class ViewPipeline:
         self.i_front = 0    # views whose front stage has been enqueued
         self.i_scatter = 0  # views whose scatter stage has been enqueued
         self.pending = {}
+
+    # records shorter than this many pairs on average: the 128-channel scatter kernel (C2 48 -> wide, C4 25 -> narrow)
+    WIDE_MIN_PAIRS_PER_RECORD = 36.0
+
+    def choose_scatter_kernel(self, n_pairs, n_headers) -> str:
+        """D % 256 == 0 may go through the 256-channel scatter kernel.  It needs fewer vector instructions per (pair,
+        channel) and leaves issue slots that the front stage can use at raised wave priority (4.08 vs 4.30 ms/view at
+        C2), but costs more per (Gaussian, tile) record: with short records (C4: 25 pairs per record) it loses 5 %, and
+        beside the 128-channel kernel the raised priority costs 6 %.  Called once without statistics (wide if the channel
+        count allows) and again by the drivers with the first views' counters."""
+        wide = (self.scatter_dim is not None and self.scatter_dim % 256 == 0 and "GWBP_NO_WIDE" not in os.environ)
+        if wide and n_pairs is not None and n_headers:
+            wide = n_pairs / n_headers >= self.WIDE_MIN_PAIRS_PER_RECORD
+        for e in self.eng:
+            e.set_narrow_scatter(not wide)
+            e.set_front_priority(wide)
+        return "wide" if wide else "narrow"
 
     def front(self, view, means, quats, scales, opacities):
         b = self.i_front % 2
@@ -171,13 +190,17 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     if view_fn is None:
         eng = engine or Engine(n, width, height, device=dev, tight_binning=True)  # same F and d, shorter tile lists
         if pipeline and len(my_views) > 1:
-            pipe = ViewPipeline(n, width, height, dev, engines=[eng, Engine(n, width, height, device=dev,
+            pipe = ViewPipeline(n, width, height, dev, scatter_dim=d_out,
+                                engines=[eng, Engine(n, width, height, device=dev,
                                                                             tight_binning=eng.tight_binning,
                                                                             isect_cap=eng.isect_cap,
                                                                             pair_cap=eng.pair_cap)])
             views = [eng.view(vm_host[v], K_host, width, height) for v in my_views]
             pipe.front(views[0], means, quats, scales, opacities)
             for i, v in enumerate(my_views):
+                if i == 2:  # one host sync per job: views 0 and 1 are counted, pick the scatter kernel for the rest
+                    st01 = pipe.stats()
+                    pipe.choose_scatter_kernel(st01["n_pairs"], st01["n_headers"])
                 if i + 1 < len(my_views):
                     pipe.front(views[i + 1], means, quats, scales, opacities)
                 feats = feature_fn(v)

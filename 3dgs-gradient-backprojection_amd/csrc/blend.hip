@@ -25,13 +25,16 @@ namespace gwbp {
 
 constexpr int kBatch = 64;
 
+template <bool HALVES> // HALVES: also emit the half-tile record lists and weight sums the 256-channel scatter kernel reads
 __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__ tile_offsets,
                                               const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
                                               Counters *__restrict__ ctr, Header *__restrict__ headers,
                                               u32 *__restrict__ hdr_count, WPair *__restrict__ wpool, u32 pair_cap,
                                               u32 *__restrict__ shards, const u32 *__restrict__ tile_order, float *__restrict__ alphas,
-                                              int dbg)
+                                              HalfHdr *__restrict__ half_a, HalfHdr *__restrict__ half_b,
+                                              u32 *__restrict__ half_cnt_a, u32 *__restrict__ half_cnt_b, int dbg, int prio)
 {
+    front_priority(prio);
     __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
     __shared__ float4 s_b[kBatch]; // ca, cb, cc, strip mask
     __shared__ float s_thr[kBatch]; // ln(255 o) + margin: sigma above this cannot reach alpha >= 1/255
@@ -63,6 +66,7 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
         Tout[q] = 1.0f;
     }
     u32 page_pos = 0, page_left = 0, npairs = 0, hdr_n = 0; // wave-uniform
+    u32 n_top = 0, n_bot = 0;                               // records with entries in tile rows 0..7 / 8..15
     bool dead = false;                                     // wave-uniform: pool exhausted
 
     for (u32 batch = beg; batch < end; batch += kBatch) {
@@ -189,15 +193,42 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
                     z.w = 0.f, z.pix = 0u;
                     wpool[page_pos + total + lane] = z;
                 }
+                // only the 256-channel scatter kernel wants the record's weight sum and the half-tile lists; computing them
+                // regardless cost the blend 15-20 % (and 7 VGPRs), hence the template parameter
+                float wsum = 0.f; // the record's share of d[gid] (k_accum_d)
+                if constexpr (HALVES) {
+                    float wl = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        wl += ((m[q] >> lane) & 1ull) ? w[q] : 0.f;
+                    wsum = wave_sum(wl);
+                }
                 if (lane == 0) {
                     Header h;
                     h.gid = (u32)__float_as_int(a.w);
                     h.woff[0] = page_pos, h.woff[1] = page_pos + base[1];
                     h.woff[2] = page_pos + base[2], h.woff[3] = page_pos + base[3];
                     h.counts = cnt[0] | (cnt[1] << 8) | (cnt[2] << 16) | (cnt[3] << 24);
-                    h.pad[0] = h.pad[1] = 0;
+                    h.wsum = (u32)__float_as_int(wsum), h.pad = 0;
                     h.mask[0] = m[0], h.mask[1] = m[1], h.mask[2] = m[2], h.mask[3] = m[3];
                     headers[beg + hdr_n] = h;
+                    // the same record as (up to) two half-tile visits for k_scatter_wide
+                    const u32 ct = HALVES ? cnt[0] + cnt[1] : 0u, cb = HALVES ? cnt[2] + cnt[3] : 0u;
+                    const u32 span = (ct != 0 && cb != 0 && n_top < (u32)kCarryRows) ? 0x100u : 0u;
+                    if (ct) {
+                        HalfHdr t;
+                        t.gid = h.gid, t.off = page_pos, t.n_span = ct | span, t.row = n_top;
+                        half_a[beg + n_top] = t;
+                    }
+                    if (cb) {
+                        HalfHdr t;
+                        t.gid = h.gid, t.off = page_pos + base[2], t.n_span = cb | span, t.row = n_top;
+                        half_b[beg + n_bot] = t;
+                    }
+                }
+                if constexpr (HALVES) {
+                    n_top += (cnt[0] + cnt[1]) ? 1u : 0u;
+                    n_bot += (cnt[2] + cnt[3]) ? 1u : 0u;
                 }
                 ++hdr_n;
             }
@@ -208,6 +239,8 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
     }
     if (lane == 0) {
         hdr_count[tile] = hdr_n;
+        if constexpr (HALVES)
+            half_cnt_a[tile] = n_top, half_cnt_b[tile] = n_bot;
         if (hdr_n)
             atomicAdd(&ctr->n_headers, hdr_n);
         if (npairs)
@@ -271,14 +304,23 @@ __global__ void k_pool_stats(const u32 *__restrict__ shards, Counters *__restric
 
 int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, hipStream_t s)
 {
+    const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
     const int n_tiles = V.tile_w * V.tile_h;
     const int fin = sort_passes(n_tiles) & 1;
+    // profiling knobs, read once per process (results are invalid when GWBP_ABLATE_BLEND is set)
+    static const int ablate = getenv("GWBP_ABLATE_BLEND") ? atoi(getenv("GWBP_ABLATE_BLEND")) : 0;
     static int extra_lds = -1; // experiment knob: pad the workgroup's LDS footprint to cap co-residency
     if (extra_lds < 0)
         extra_lds = getenv("GWBP_BLEND_LDS") ? atoi(getenv("GWBP_BLEND_LDS")) : 0;
-    hipLaunchKernelGGL(k_blend, dim3(n_tiles), dim3(64), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d, W.counters,
-                       W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, W.tile_order, alphas,
-                       getenv("GWBP_ABLATE_BLEND") ? atoi(getenv("GWBP_ABLATE_BLEND")) : 0);
+#define GWBP_BLEND(H)                                                                                                 \
+    hipLaunchKernelGGL(k_blend<H>, dim3(n_tiles), dim3(64), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d,  \
+                       W.counters, W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, W.tile_order, alphas,  \
+                       W.half[0], W.half[1], W.half_count[0], W.half_count[1], ablate, prio)
+    if (L.flags & GWBP_FLAG_NARROW_SCATTER)
+        GWBP_BLEND(false);
+    else
+        GWBP_BLEND(true);
+#undef GWBP_BLEND
     hipLaunchKernelGGL(k_pool_stats, dim3(1), dim3(1), 0, s, W.shards, W.counters);
     return check_hip(hipGetLastError(), "blend launch");
 }

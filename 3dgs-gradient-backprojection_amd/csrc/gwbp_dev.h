@@ -49,10 +49,24 @@ struct __attribute__((aligned(64))) Header {
     u32 gid;
     u32 woff[4];
     u32 counts;
-    u32 pad[2];
+    u32 wsum; // float bits: sum of the record's weights = the record's share of d[gid] (k_accum_d)
+    u32 pad;
     u64 mask[4];
 };
 static_assert(sizeof(Header) == 64, "header is one 64-B line");
+
+// The same records once more, split into the tile's TOP half (rows 0..7 = quarters 0,1) and BOTTOM half (quarters 2,3)
+// for k_scatter_wide, which stages half-tile slabs of 256 channels: list A / list B of a tile hold only the records
+// that have entries in that half (so no wave ever claims an empty visit).  A record present in both halves carries its
+// partial sums from the top to the bottom pass through row `row` of the workgroup's carry buffer.
+struct __attribute__((aligned(16))) HalfHdr {
+    u32 gid;
+    u32 off;    // first entry of this half in the weight store (the half's entries are contiguous)
+    u32 n_span; // entries in this half (1..128) | spans-both-halves-and-has-a-carry-row << 8
+    u32 row;    // carry row: the record's index in list A of its tile (valid when the span bit is set)
+};
+constexpr int kCarryRows = 1024; // carry rows per scatter workgroup; records of list A beyond it are flushed per half
+constexpr int kCarryWgs = 256;   // scatter workgroups that own a carry slice (persistent grid: one per CU)
 
 // Mirrors gwbp_stats (include/gwbp.h) field for field.
 struct Counters {
@@ -69,7 +83,7 @@ static_assert(sizeof(Counters) == sizeof(gwbp_stats), "Counters must mirror gwbp
 struct Layout {
     size_t total;
     size_t counters, shards, g2d, rect, touched, blocksums, dkeys[2], dvals[2], keys[2], vals[2], hist, digit_total, tile_offsets, tile_order, hdr_count,
-        headers, wpool;
+        headers, half[2], half_count[2], carry, wpool;
     int64_t n, isect_cap, pair_cap;
     int max_tiles, n_scan_blocks, n_sort_blocks, scatter_wgs, flags;
 };
@@ -90,6 +104,9 @@ struct Ws {
     u32 *tile_order; // tiles by descending list length (heavy tiles start first in k_blend)
     u32 *hdr_count;
     Header *headers;
+    HalfHdr *half[2];    // [0] top-half records, [1] bottom-half records, indexed like headers (tile_offsets[t] + i)
+    u32 *half_count[2];  // per tile
+    float *carry;        // kCarryWgs x kCarryRows x 256 floats
     WPair *wpool;
 };
 
@@ -141,6 +158,8 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap
                    float scale_d, float *F, float *d, hipStream_t s);
 int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
                         float scale_d, float *F, float *d, hipStream_t s);
+int launch_scatter_wide(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
+                        float *F, hipStream_t s);
 int launch_render(const Layout &L, const Ws &W, const ViewDev &V, const float *colors, int D, float *out,
                   hipStream_t s);
 int launch_render_px(const Ws &W, const ViewDev &V, const float *colors, int D, float *out, float *alphas,
@@ -183,6 +202,32 @@ __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi
 __device__ __forceinline__ u32 mbcnt(u64 mask)
 {
     return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+// GWBP_FLAG_FRONT_PRIORITY: the front-stage kernels (project / sort / blend of view v+1) raise their waves' issue
+// priority.  Beside the persistent scatter kernel of view v the SIMD arbiter otherwise serves the four older scatter waves
+// first and the front's dependent instruction chains stretch 3x (k_blend 1.0 -> 2.9 ms at equal occupancy).
+__device__ __forceinline__ void front_priority(int on)
+{
+    if (on)
+        __builtin_amdgcn_s_setprio(3);
+}
+// Sum over the 64 lanes, returned wave-uniform: four DPP adds inside each row of 16 lanes, then the four row totals.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_f<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v); // row_half_mirror
+    v += dpp_f<0x140>(v); // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ u32 uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 uniform64(u64 v)

@@ -16,8 +16,9 @@ __global__ __launch_bounds__(kScanBlock) void k_project(
     const float *__restrict__ scales, const float *__restrict__ opac, G2D *__restrict__ g2d,
     uint2 *__restrict__ rect, u32 *__restrict__ touched, u32 *__restrict__ dkeys, u32 *__restrict__ dvals,
     Counters *__restrict__ ctr, int32_t *__restrict__ o_radii, float *__restrict__ o_means2d, float *__restrict__ o_depths,
-    float *__restrict__ o_conics, int tight)
+    float *__restrict__ o_conics, int tight, int prio)
 {
+    front_priority(prio);
     const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
     u32 ntiles = 0;
     G2D g;
@@ -183,8 +184,9 @@ __global__ __launch_bounds__(kScanBlock) void k_project(
 // Block totals of tiles touched, taken in DEPTH-SORTED Gaussian order (input of the scan that places the emit).
 __global__ __launch_bounds__(kScanBlock) void k_sorted_blocksums(int64_t N, const u32 *__restrict__ order,
                                                                  const u32 *__restrict__ touched,
-                                                                 u32 *__restrict__ blocksums)
+                                                                 u32 *__restrict__ blocksums, int prio)
 {
+    front_priority(prio);
     const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
     u32 v = (i < N) ? touched[order[i]] : 0u;
     __shared__ u32 s_sum[kScanBlock / 64];
@@ -208,8 +210,9 @@ __global__ __launch_bounds__(kScanBlock) void k_sorted_blocksums(int64_t N, cons
 // scatter workgroups the dispatcher can wait milliseconds for that (2.9 ms measured with a 12-wave scatter kernel).
 constexpr int kSumThreads = 256;
 __global__ __launch_bounds__(kSumThreads) void k_scan_blocksums(int nblk, u32 *__restrict__ blocksums,
-                                                                Counters *__restrict__ ctr, u32 isect_cap)
+                                                                Counters *__restrict__ ctr, u32 isect_cap, int prio)
 {
+    front_priority(prio);
     __shared__ u32 s_wave[kSumThreads / 64];
     __shared__ u32 s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -261,8 +264,9 @@ __global__ __launch_bounds__(kScanBlock) void k_emit(int64_t N, int tile_w, cons
                                                      const u32 *__restrict__ touched,
                                                      const u32 *__restrict__ blocksums,
                                                      const Counters *__restrict__ ctr, u32 *__restrict__ keys,
-                                                     u32 *__restrict__ vals)
+                                                     u32 *__restrict__ vals, int prio)
 {
+    front_priority(prio);
     if (ctr->overflow & 1u)
         return;
     const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
@@ -298,12 +302,13 @@ __global__ __launch_bounds__(kScanBlock) void k_emit(int64_t N, int tile_w, cons
 
 int launch_emit(const Layout &L, const Ws &W, const ViewDev &V, const u32 *order, hipStream_t s)
 {
+    const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
     hipLaunchKernelGGL(k_sorted_blocksums, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, order, W.touched,
-                       W.blocksums);
+                       W.blocksums, prio);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(kSumThreads), 0, s, L.n_scan_blocks, W.blocksums, W.counters,
-                       (u32)L.isect_cap);
+                       (u32)L.isect_cap, prio);
     hipLaunchKernelGGL(k_emit, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, V.tile_w, order, W.rect, W.touched,
-                       W.blocksums, W.counters, W.keys[0], W.vals[0]);
+                       W.blocksums, W.counters, W.keys[0], W.vals[0], prio);
     return check_hip(hipGetLastError(), "emit launch");
 }
 
@@ -311,6 +316,7 @@ int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *
                    const float *scales, const float *opac, int32_t *radii, float *means2d, float *depths,
                    float *conics, hipStream_t s)
 {
+    const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
     // counters and the pool shard heads are adjacent sub-buffers: one memset node
     int rc = check_hip(hipMemsetAsync(W.counters, 0, (size_t)((char *)W.shards - (char *)W.counters) + (kShards + kQueues) * 64, s),
                        "memset counters");
@@ -320,7 +326,7 @@ int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *
         return GWBP_OK;
     hipLaunchKernelGGL(k_project, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, V, means, quats, scales, opac,
                        W.g2d, W.rect, W.touched, W.dkeys[0], W.dvals[0], W.counters, radii, means2d, depths, conics,
-                       L.flags & GWBP_FLAG_TIGHT_BINNING);
+                       L.flags & GWBP_FLAG_TIGHT_BINNING, prio);
     return check_hip(hipGetLastError(), "project launch");
 }
 

@@ -240,6 +240,20 @@ static int chunk_pitch(int D)
     return (p + 3) & ~3; // multiple of 4 floats: 16-B LDS rows, even for the b64 channel pairs
 }
 
+// d[g] += scale_d * (sum of the record's weights), one thread per (Gaussian, tile) record; the sums were taken by
+// k_blend (Header::wsum).  Used with k_scatter_wide, whose counted-wait visit loop has no room for a conditional
+// denominator operation.
+__global__ __launch_bounds__(256) void k_accum_d(const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
+                                                 const Header *__restrict__ headers, float scale_d,
+                                                 float *__restrict__ dsum_out)
+{
+    const int tile = blockIdx.x;
+    const u32 nh = hdr_count[tile];
+    const Header *hb = headers + tile_offsets[tile];
+    for (u32 h = threadIdx.x; h < nh; h += blockDim.x)
+        atomicAdd(dsum_out + hb[h].gid, __int_as_float((int)hb[h].wsum) * scale_d);
+}
+
 int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
                    float scale_d, float *F, float *d, hipStream_t s)
 {
@@ -257,7 +271,13 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap
             return rc;
         attr_done = true;
     }
-    // fast paths (scatter_full.hip): D % 128 == 0 or D <= 64, any strides
+    // fast paths: D % 256 == 0 channel-contiguous (scatter_wide.hip); D % 128 == 0 or D <= 64, any strides (scatter_full.hip)
+    static const bool no_wide = getenv("GWBP_NO_WIDE") != nullptr; // A/B knob
+    if (D % 256 == 0 && M.fs_c == 1 && !no_wide && !(L.flags & GWBP_FLAG_NARROW_SCATTER)) {
+        if (d && n_tiles > 0)
+            hipLaunchKernelGGL(k_accum_d, dim3(n_tiles), dim3(256), 0, s, W.tile_offsets, W.hdr_count, W.headers, scale_d, d);
+        return launch_scatter_wide(L, W, V, M, D, scale_f, F, s);
+    }
     if (D % kChunk == 0 || D <= 64)
         return launch_scatter_full(L, W, V, M, D, scale_f, scale_d, F, d, s);
     else

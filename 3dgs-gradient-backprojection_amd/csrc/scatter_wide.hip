@@ -1,0 +1,347 @@
+// scatter_wide.hip -- k_scatter_wide: the D % 256 == 0, channel-contiguous path of the weighted scatter-accumulate
+// (C2 D = 512, C4 D = 768, dino-sized 1024); semantics identical to k_scatter / k_scatter_full.
+//
+//   F[g, c0:c0+256] += sum_p w_g(p) * feats[p, c0:c0+256]        (backproject.py:127-131 via colors.grad)
+//
+// Why a second fast path: k_scatter_full spends 4 vector instructions per (pair, 128 channels) -- 2 v_readlane,
+// 1 address add, 1 v_pk_fma_f32 -- and is VALU-issue bound.  With 4 channels per lane (ds_read_b128 + 2 v_pk_fma_f32)
+// the two v_readlane and the address add are shared by 256 channels: 2.5 instructions per (pair, 128 channels)
+// (tools/ubench_scatter.hip mode 5: 1.53x the per-channel rate of mode 0).  The price is LDS capacity: 256 px x 256 ch
+// x 4 B does not fit, so a work item = (tile, 256-channel chunk) runs in TWO passes over half-tile slabs
+// (tile rows 0..7, then 8..15; 128 px x 256 ch = 128 KB each).  The flush traffic must not grow with it -- fp32
+// atomics run memory-side at ~1.3 TB/s chip-wide and the per-(Gaussian, tile) flush already sits at ~75 % of that --
+// so a record with entries in both halves is NOT flushed twice: the top pass parks its partial sums in a carry row
+// (plain stores into a per-workgroup slice that stays in L2), the bottom pass starts from them and issues the one
+// atomic flush.  k_blend hands over the records as two per-tile lists (HalfHdr), so no wave ever claims an empty visit.
+//
+// Slab layout: row = pixel (1 KB), position 4*l + k of a row holds channel c0 + 64*k + l.  Lane l reads its 16 B with
+// one conflict-free ds_read_b128 and owns channels {l, l+64, l+128, l+192}: the flush is four 256-B contiguous
+// atomic wave-instructions with no cross-lane transpose.  Staging loads are therefore dword loads (256 B per
+// wave-instruction, coalesced) feeding one ds_write_b128 per (pixel, lane).
+//
+// Every VMEM instruction of a visit is unconditional (6 loads, 4 flush operations), so the counted s_waitcnt in front
+// of a visit's entries is exact: vmcnt(10) (scatter_full.hip explains why it must be).  The denominator d is not
+// accumulated here: k_blend leaves every record's weight sum in its header and k_accum_d (scatter.hip) adds them --
+// a fifth, conditional operation per visit would break the count, and a stand-in for it cost more than the kernel
+// saved (in-kernel d with a stand-in store: 4.51 ms/view in the pipeline; k_accum_d: 4.25).  experiments/r1_scatter_wide/README.md has the measurements and the pitfalls of the first attempt.
+
+#include <stdlib.h>
+
+#include "gwbp_dev.h"
+
+namespace gwbp {
+
+namespace {
+
+constexpr int kWide = 256;            // channels per chunk
+constexpr int kHalfPix = kTilePix / 2; // pixels per slab
+constexpr int kThreads = 1024;
+constexpr int kSlabFloats = kHalfPix * kWide; // 32768 floats = 128 KB
+constexpr size_t kLdsBytes = (size_t)kSlabFloats * 4 + 16; // slab + work counter + two item slots
+
+struct Visit { // wave-uniform description of one (record, half) visit
+    u32 gid;
+    u32 off;  // first entry
+    u32 n;    // entries (1..128)
+    u32 span; // nonzero: the record has entries in both halves and owns carry row `row`
+    u32 row;
+};
+
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ u32 readlane_u(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+
+struct EV { // entries 64j .. 64j+63 of a visit, one per lane
+    float w;
+    u32 pix;
+};
+struct Pre { // everything a visit prefetches: two entry vectors and the four carry dwords of this lane
+    EV e[2];
+    float c[4];
+};
+// tied operands: see scatter_full.hip (the load must land in the registers the struct lives in)
+__device__ __forceinline__ void issue_e(EV &dst, const WPair *p)
+{
+    asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(*reinterpret_cast<float2 *>(&dst)) : "v"(p) : "memory");
+}
+// sc1: served by L2, never by this CU's L1 (the row was written by another wave of this workgroup one pass earlier)
+__device__ __forceinline__ void issue_c(float &dst, const float *p)
+{
+    asm volatile("global_load_dword %0, %1, off sc1" : "+v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_pre(Pre &x)
+{
+    asm volatile("s_waitcnt vmcnt(%6)"
+                 : "+v"(*reinterpret_cast<float2 *>(&x.e[0])), "+v"(*reinterpret_cast<float2 *>(&x.e[1])),
+                   "+v"(x.c[0]), "+v"(x.c[1]), "+v"(x.c[2]), "+v"(x.c[3])
+                 : "n"(N)
+                 : "memory");
+}
+
+constexpr int kLoads = 6;  // VMEM loads per visit (prefetch)
+constexpr int kFlush = 4;  // VMEM flush operations per visit
+
+__global__ __launch_bounds__(kThreads) void k_scatter_wide(
+    ViewDev V, int n_chunks, const u32 *__restrict__ tile_offsets, const u32 *__restrict__ cnt_a,
+    const u32 *__restrict__ cnt_b, const HalfHdr *__restrict__ half_a, const HalfHdr *__restrict__ half_b,
+    const WPair *__restrict__ wpool, FeatMap M, int D, float scale_f, float *__restrict__ F,
+    u32 *__restrict__ queues, float *__restrict__ carry_all, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    u32 *s_next = reinterpret_cast<u32 *>(lds + kSlabFloats);
+    u32 *s_item = s_next + 1; // two slots: iteration k reads [k & 1], thread 0 fills [(k + 1) & 1] meanwhile
+
+    // persistent workgroups, per-XCD-class queues: as k_scatter_full
+    const u32 xcls = blockIdx.x & 7u;
+    const int n_tiles = V.tile_w * V.tile_h;
+    const u32 n_items = (u32)((n_tiles - (int)xcls + 7) / 8) * (u32)n_chunks;
+    u32 *queue = queues + xcls * 16;
+    const int lane = threadIdx.x & 63;
+    float *carry = carry_all + (size_t)blockIdx.x * kCarryRows * kWide; // this workgroup's slice
+    const float *feats = M.p;
+    if (threadIdx.x == 0)
+        s_item[0] = atomicAdd(queue, 1u);
+    __syncthreads();
+    for (u32 k = 0;; ++k) {
+    const u32 item = uniform(s_item[k & 1u]); // wave-uniform by construction: keep every derived address scalar
+    if (item >= n_items)
+        break;
+    const int chunk = (int)(item % (u32)n_chunks);
+    const int tile = (int)((item / (u32)n_chunks) * 8u + xcls);
+    const int tx = tile % V.tile_w, ty = tile / V.tile_w;
+    const int c0 = chunk * kWide;
+
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+    const u32 nh = uniform(phase ? cnt_b[tile] : cnt_a[tile]);
+    const HalfHdr *hbase = (phase ? half_b : half_a) + tile_offsets[tile];
+    if (threadIdx.x == 0)
+        *s_next = 0;
+    u32 nxt = 0;
+    if (phase == 0 && threadIdx.x == 0)
+        nxt = atomicAdd(queue, 1u); // claim the next item under the slab loads
+    if (!(dbg & 4) && nh != 0) {
+        // stage 128 px x 256 ch: unit = (pixel, lane) -> 4 coalesced dword loads + one ds_write_b128; 8 units per thread
+        constexpr int kAll = kHalfPix * 64;                          // 8192 (pixel, lane) units
+        constexpr int kUnits = (kAll + kThreads - 1) / kThreads;     // 8 at 1024 threads
+        float4 vals[kUnits];
+        int64_t offs[kUnits]; // pixel offsets first: with index maps they are loads themselves, and must not sit
+                              // between the feature loads (their wait would serialise the slab fetch)
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            const int idx = min(u * kThreads + (int)threadIdx.x, kAll - 1);
+            const int p = idx >> 6; // 0..127 inside the half; l = idx & 63 = lane
+            const int pix = phase * kHalfPix + p;
+            const int ix = tx * kTile + (pix & 15), iy = ty * kTile + (pix >> 4);
+            // pixels past the image edge are never referenced by an entry: load a clamped (valid) address
+            offs[u] = M.pixel(min(iy, V.H - 1), min(ix, V.W - 1));
+        }
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            const float *src = feats + offs[u] + c0 + lane;
+            vals[u] = make_float4(src[0], src[64], src[128], src[192]);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            const int idx = u * kThreads + threadIdx.x;
+            if (kAll % kThreads == 0 || idx < kAll)
+                *reinterpret_cast<float4 *>(lds + (idx >> 6) * kWide + 4 * lane) = vals[u];
+        }
+    }
+    if (phase == 0 && threadIdx.x == 0)
+        s_item[(k + 1u) & 1u] = nxt;
+    __syncthreads();
+
+    const u32 lane_base = (u32)(lane * 16);
+    const char *slab = reinterpret_cast<const char *>(lds);
+
+    auto claim = [&]() __attribute__((always_inline)) -> u32 {
+        u32 h = 0;
+        if (lane == 0)
+            h = atomicAdd(s_next, 1u);
+        return uniform(h);
+    };
+    auto load_visit = [&](u32 h) __attribute__((always_inline)) -> Visit { // scalar loads; an invalid claim re-reads the last header (never processed)
+        const HalfHdr *hp = hbase + min(h, nh - 1);
+        Visit r;
+        r.gid = uniform(hp->gid);
+        r.off = uniform(hp->off);
+        const u32 ns = uniform(hp->n_span);
+        r.n = ns & 0xFFu;
+        r.span = ns & 0x100u;
+        r.row = uniform(hp->row);
+        return r;
+    };
+    auto prefetch = [&](const Visit &R, Pre &x) __attribute__((always_inline)) { // exactly kLoads VMEM loads
+        const u32 last = R.n - 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            issue_e(x.e[j], wpool + (R.off + min((u32)(64 * j + lane), last)));
+        // carry dwords of this lane (top pass and non-spanning records: row 0, value ignored)
+        const float *cr = carry + (size_t)((phase && R.span) ? R.row : 0u) * kWide + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            issue_c(x.c[q], cr + 64 * q);
+    };
+
+    float4 acc;
+    // n in 1..64 entries held by lanes 0..n-1 of ev (lanes >= n: w = 0, pix = any pixel)
+    auto run_vec = [&](const EV &ev, u32 n) __attribute__((always_inline)) {
+        // ONE batch of 8 float4 in flight (32 VGPRs): the other waves of the SIMD cover the LDS latency between the
+        // eight reads and the first FMA.  Two batches (the k_scatter_full scheme) put this kernel at 117 VGPRs: 16 waves
+        // then own the CU's register file, the overlapped front-stage kernels cannot co-reside and the two-stream
+        // pipeline degenerates to the serial schedule.  At 83 VGPRs the front runs beside it as with k_scatter_full.
+        constexpr int kB = 8;
+        float4 f[kB];
+#define GWBP_ISSUE8(B)                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                    \
+    {                                                                                                                 \
+        const u32 px_ = readlane_u(ev.pix, kB * (B) + j);                                                             \
+        f[j] = *reinterpret_cast<const float4 *>(slab + (((px_ & 127u) << 10) + lane_base));                          \
+    }
+#define GWBP_FMA8(B)                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                    \
+    {                                                                                                                 \
+        const float w = readlane_f(ev.w, kB * (B) + j);                                                               \
+        acc.x = __builtin_fmaf(w, f[j].x, acc.x);                                                                     \
+        acc.y = __builtin_fmaf(w, f[j].y, acc.y);                                                                     \
+        acc.z = __builtin_fmaf(w, f[j].z, acc.z);                                                                     \
+        acc.w = __builtin_fmaf(w, f[j].w, acc.w);                                                                     \
+    }
+#pragma unroll
+        for (int B = 0; B < 64 / kB; ++B) {
+            if ((u32)kB * B >= n)
+                break;
+            GWBP_ISSUE8(B)
+            GWBP_FMA8(B)
+        }
+#undef GWBP_ISSUE8
+#undef GWBP_FMA8
+    };
+    auto process = [&](const Visit &R, const Pre &x) __attribute__((always_inline)) { // exactly kFlush VMEM operations
+        const bool resume = phase && R.span;
+        acc = resume ? make_float4(x.c[0], x.c[1], x.c[2], x.c[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(dbg & 2)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if ((u32)(64 * j) >= R.n)
+                    break;
+                const u32 n = min(64u, R.n - 64u * j);
+                EV ev;
+                ev.w = ((u32)lane < n) ? x.e[j].w : 0.f; // clamped loads / the other half's entries: zero them
+                ev.pix = x.e[j].pix;
+                run_vec(ev, n);
+            }
+        }
+        if (!phase && R.span) { // park the partial sums: plain stores, same shape as the atomics
+            float *cr = carry + (size_t)R.row * kWide + lane;
+            cr[0] = acc.x, cr[64] = acc.y, cr[128] = acc.z, cr[192] = acc.w;
+        } else {
+            float *Fg = F + (int64_t)R.gid * D + c0 + lane;
+            if (!(dbg & 1)) {
+                atomicAdd(Fg, acc.x * scale_f);
+                atomicAdd(Fg + 64, acc.y * scale_f);
+                atomicAdd(Fg + 128, acc.z * scale_f);
+                atomicAdd(Fg + 192, acc.w * scale_f);
+            } else { // ablation: same VMEM count, no atomics
+                __builtin_nontemporal_store(acc.x * scale_f, Fg);
+                __builtin_nontemporal_store(acc.y * scale_f, Fg + 64);
+                __builtin_nontemporal_store(acc.z * scale_f, Fg + 128);
+                __builtin_nontemporal_store(acc.w * scale_f, Fg + 192);
+            }
+        }
+    };
+
+    // visit pipeline: header scalar loads two visits ahead, entry + carry loads one visit ahead (A/B buffers)
+    Pre pA = {{{0.f, 0u}, {0.f, 0u}}, {0.f, 0.f, 0.f, 0.f}}, pB = pA;
+    u32 h = claim();
+    if (h < nh) {
+        Visit Rcur = load_visit(h);
+        prefetch(Rcur, pA);
+        h = claim();
+        bool vnxt = h < nh;
+        Visit Rnxt = load_visit(h);
+
+        // peeled first visit: only loads(1) are guaranteed younger than loads(0)
+        prefetch(Rnxt, pB);
+        h = claim();
+        bool vnn = h < nh;
+        Visit Rnn = load_visit(h);
+        wait_pre<kLoads>(pA);
+        process(Rcur, pA);
+        while (vnxt) {
+            // odd: current visit's data in pB; next loads into pA
+            Rcur = Rnxt, Rnxt = Rnn, vnxt = vnn;
+            prefetch(Rnxt, pA);
+            h = claim();
+            vnn = h < nh;
+            Rnn = load_visit(h);
+            wait_pre<kLoads + kFlush>(pB);
+            process(Rcur, pB);
+            if (!vnxt)
+                break;
+            // even: current in pA; next into pB
+            Rcur = Rnxt, Rnxt = Rnn, vnxt = vnn;
+            prefetch(Rnxt, pB);
+            h = claim();
+            vnn = h < nh;
+            Rnn = load_visit(h);
+            wait_pre<kLoads + kFlush>(pA);
+            process(Rcur, pA);
+        }
+    }
+    // Drain: (1) the last prefetch still targets pA/pB's registers, (2) the carry rows parked in the top pass must be
+    // in L2 before any wave of the bottom pass loads them, (3) the slab is about to be overwritten.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    } // phase
+    } // item loop
+    // the last workgroup of the class to leave re-arms the queue (see k_scatter_full)
+    if (threadIdx.x == 0) {
+        const u32 left = atomicAdd(queue + 1, 1u);
+        if (left == gridDim.x / 8u - 1u) {
+            atomicExch(queue + 1, 0u);
+            atomicExch(queue, 0u);
+        }
+    }
+}
+
+} // namespace
+
+int launch_scatter_wide(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
+                        float *F, hipStream_t s)
+{
+    static bool attr_done = false; // benign race: idempotent
+    if (!attr_done) {
+        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes),
+                                 "scatter_wide LDS attribute");
+        if (rc)
+            return rc;
+        attr_done = true;
+    }
+    static const char *ab = getenv("GWBP_ABLATE"); // profiling ablation only, read once (results are invalid when set)
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return set_error(GWBP_EINVAL, "cannot query the device for the persistent scatter grid");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    // persistent workgroups: one per CU, at most kCarryWgs (each owns a carry slice), a multiple of the 8 XCD classes
+    int grid = L.scatter_wgs > 0 ? L.scatter_wgs : n_cu;
+    grid = (grid + 7) & ~7;
+    if (grid > kCarryWgs)
+        grid = kCarryWgs;
+    u32 *queues = W.shards + kShards * 16;
+    hipLaunchKernelGGL(k_scatter_wide, dim3(grid), dim3(kThreads), kLdsBytes, s, V, D / kWide, W.tile_offsets,
+                       W.half_count[0], W.half_count[1], W.half[0], W.half[1], W.wpool, M, D, scale_f, F, queues, W.carry,
+                       ab ? atoi(ab) : 0);
+    return check_hip(hipGetLastError(), "scatter_wide launch");
+}
+
+} // namespace gwbp

@@ -24,8 +24,9 @@ constexpr int kWaves = kSortThreads / 64;
 constexpr int kWaveItems = kSortItems / kWaves; // 1024 keys per wave segment
 
 __global__ __launch_bounds__(kSortThreads) void k_hist(const u32 *__restrict__ keys, const u32 *__restrict__ n_dev,
-                                                       u32 n_host, int shift, int nblk, u32 *__restrict__ hist)
+                                                       u32 n_host, int shift, int nblk, u32 *__restrict__ hist, int prio)
 {
+    front_priority(prio);
     const u32 n = n_dev ? *n_dev : n_host;
     const u32 base = blockIdx.x * (u32)kSortItems;
     __shared__ u32 s_h[256];
@@ -44,8 +45,9 @@ __global__ __launch_bounds__(kSortThreads) void k_hist(const u32 *__restrict__ k
 }
 
 // block d: exclusive scan of hist[d][0..nblk) in place, digit_total[d] = sum
-__global__ __launch_bounds__(256) void k_scan(int nblk, u32 *__restrict__ hist, u32 *__restrict__ digit_total)
+__global__ __launch_bounds__(256) void k_scan(int nblk, u32 *__restrict__ hist, u32 *__restrict__ digit_total, int prio)
 {
+    front_priority(prio);
     u32 *row = hist + (size_t)blockIdx.x * nblk;
     __shared__ u32 s_wave[4];
     __shared__ u32 s_carry;
@@ -87,8 +89,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u32 *__res
                                                                 u32 *__restrict__ vals_out,
                                                                 const u32 *__restrict__ n_dev, u32 n_host, int shift,
                                                                 int nblk, const u32 *__restrict__ hist,
-                                                                const u32 *__restrict__ digit_total)
+                                                                const u32 *__restrict__ digit_total, int prio)
 {
+    front_priority(prio);
     const u32 n = n_dev ? *n_dev : n_host;
     const u32 base = blockIdx.x * (u32)kSortItems;
     if (base >= n)
@@ -174,8 +177,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u32 *__res
 // isect_offset_encode: offsets[t] = first index whose tile >= t; offsets[n_tiles] = n.
 __global__ __launch_bounds__(256) void k_tile_offsets(const u32 *__restrict__ keys,
                                                       const Counters *__restrict__ ctr, int n_tiles,
-                                                      u32 *__restrict__ offsets)
+                                                      u32 *__restrict__ offsets, int prio)
 {
+    front_priority(prio);
     const u32 n = ctr->n_isect;
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (n == 0) {
@@ -216,8 +220,9 @@ __global__ void k_export_sorted(const u32 *__restrict__ keys, const u32 *__restr
 // k_scan_blocksums).
 constexpr int kOrderThreads = 256;
 __global__ __launch_bounds__(kOrderThreads) void k_tile_order(const u32 *__restrict__ tile_offsets, int n_tiles,
-                                                              u32 *__restrict__ order)
+                                                              u32 *__restrict__ order, int prio)
 {
+    front_priority(prio);
     __shared__ u32 s_cnt[1024];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -269,25 +274,26 @@ __global__ void k_copy_u32(const u32 *__restrict__ src, int32_t *__restrict__ ds
 }
 
 static void radix_passes(const Ws &W, u32 *const keys[2], u32 *const vals[2], const u32 *n_dev, u32 n_host, int nblk,
-                         int passes, hipStream_t s)
+                         int passes, int prio, hipStream_t s)
 {
     for (int p = 0; p < passes; ++p) {
         const int in = p & 1, out = in ^ 1;
-        hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(kSortThreads), 0, s, keys[in], n_dev, n_host, p * 8, nblk, W.hist);
-        hipLaunchKernelGGL(k_scan, dim3(256), dim3(256), 0, s, nblk, W.hist, W.digit_total);
+        hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(kSortThreads), 0, s, keys[in], n_dev, n_host, p * 8, nblk, W.hist, prio);
+        hipLaunchKernelGGL(k_scan, dim3(256), dim3(256), 0, s, nblk, W.hist, W.digit_total, prio);
         hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(kSortThreads), 0, s, keys[in], vals[in], keys[out],
-                           vals[out], n_dev, n_host, p * 8, nblk, W.hist, W.digit_total);
+                           vals[out], n_dev, n_host, p * 8, nblk, W.hist, W.digit_total, prio);
     }
 }
 
 int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *isect_ids, int32_t *flatten_ids,
                     int32_t *tile_offsets, hipStream_t s)
 {
+    const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
     const int n_tiles = V.tile_w * V.tile_h;
     if (L.n > 0) {
         // level 1: Gaussians by depth (4 passes -> the result is back in buffer 0)
         const int nblk1 = (int)((L.n + kSortItems - 1) / kSortItems);
-        radix_passes(W, W.dkeys, W.dvals, nullptr, (u32)L.n, nblk1, 4, s);
+        radix_passes(W, W.dkeys, W.dvals, nullptr, (u32)L.n, nblk1, 4, prio, s);
         // emit intersections front to back
         int rc = launch_emit(L, W, V, W.dvals[0], s);
         if (rc)
@@ -296,12 +302,12 @@ int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *ise
     // level 2: intersections by tile id
     const int passes = sort_passes(n_tiles);
     const int nblk2 = (int)((L.isect_cap + kSortItems - 1) / kSortItems);
-    radix_passes(W, W.keys, W.vals, &W.counters->n_isect, 0u, nblk2, passes, s);
+    radix_passes(W, W.keys, W.vals, &W.counters->n_isect, 0u, nblk2, passes, prio, s);
     const int fin = passes & 1;
     const int ob = (int)((L.isect_cap + 255) / 256);
     hipLaunchKernelGGL(k_tile_offsets, dim3(ob > 0 ? ob : 1), dim3(256), 0, s, W.keys[fin], W.counters, n_tiles,
-                       W.tile_offsets);
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kOrderThreads), 0, s, W.tile_offsets, n_tiles, W.tile_order);
+                       W.tile_offsets, prio);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kOrderThreads), 0, s, W.tile_offsets, n_tiles, W.tile_order, prio);
     if (isect_ids || flatten_ids)
         hipLaunchKernelGGL(k_export_sorted, dim3(1024), dim3(256), 0, s, W.keys[fin], W.vals[fin], W.g2d, W.counters,
                            L.isect_cap, isect_ids, flatten_ids);

@@ -59,9 +59,27 @@ class Engine:
         self.tight_binning = bool(tight_binning)
         self._alloc()
 
+    def set_front_priority(self, on: bool) -> None:
+        """GWBP_FLAG_FRONT_PRIORITY for this engine's project / bin_sort / blend_weights launches: raised wave priority.
+        Only useful when they run on a second stream beside a D % 256 == 0 scatter (ViewPipeline sets it)."""
+        if on:
+            self.caps.flags |= _lib.FLAG_FRONT_PRIORITY
+        else:
+            self.caps.flags &= ~_lib.FLAG_FRONT_PRIORITY
+
+    def set_narrow_scatter(self, on: bool) -> None:
+        """GWBP_FLAG_NARROW_SCATTER: the 128-channel scatter kernel even when D % 256 == 0 (short records, see gwbp.h).
+        An Engine starts narrow (k_blend then skips the half-tile lists only the 256-channel kernel reads); whoever
+        knows that a D % 256 == 0 scatter follows switches it off BEFORE blend_weights of that view (ViewPipeline,
+        the drop-in operator)."""
+        if on:
+            self.caps.flags |= _lib.FLAG_NARROW_SCATTER
+        else:
+            self.caps.flags &= ~_lib.FLAG_NARROW_SCATTER
+
     def _alloc(self):
         self.caps = Caps(self.n, self.isect_cap, self.pair_cap, self.max_w, self.max_h, self.scatter_workgroups,
-                         _lib.FLAG_TIGHT_BINNING if self.tight_binning else 0)
+                         (_lib.FLAG_TIGHT_BINNING if self.tight_binning else 0) | _lib.FLAG_NARROW_SCATTER)
         nbytes = C.c_size_t(0)
         check(self.lib.gwbp_workspace_size(C.byref(self.caps), C.byref(nbytes)), "gwbp_workspace_size")
         self.ws_bytes = int(nbytes.value)

@@ -55,6 +55,9 @@ class _Rasterize(torch.autograd.Function):
         view = eng.view(viewmat, K, width, height, **kw)
         D = colors.shape[1]
         need_store = colors.requires_grad or D > 4  # the weight store is only needed for backward / the wide render
+        # a backward with D % 256 == 0 channels goes through the 256-channel scatter kernel, which needs the blend's
+        # half-tile lists: the flag must be in place before this view's blend
+        eng.set_narrow_scatter(not (colors.requires_grad and D % 256 == 0))
         proj, bins, alphas, st = _run_front(eng, view, means, quats, scales, opacities, D > 4, holder is not None,
                                             want_store=need_store)
         if D <= 4:  # RGB / RGB+D / depth: pixel-parallel rasteriser straight from the sorted tile lists
@@ -80,6 +83,7 @@ class _Rasterize(torch.autograd.Function):
         if eng.generation != ctx.gen or eng.n != means.shape[0] or not ctx.has_store:
             # the workspace was reused by another call since forward: rebuild this view's weight store
             eng = get_engine(means.device, means.shape[0], view.width, view.height)
+            eng.set_narrow_scatter(ctx.shape[1] % 256 != 0)
             _run_front(eng, view, means, quats, scales, opacities, False, False)
         v_colors = torch.zeros(ctx.shape, device=means.device, dtype=torch.float32)
         eng.scatter(view, g_out, v_colors, None)

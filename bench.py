@@ -98,7 +98,7 @@ def main():
         pipe, accum = None, torch.zeros(32, dtype=torch.uint8, device=dev)
     else:
         eng2 = gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap, tight_binning=tight)
-        pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng, eng2])
+        pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng, eng2], scatter_dim=D)
         accum = pipe.accum
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
@@ -140,6 +140,13 @@ def main():
         front(i + 1)
         scatter(i)
     torch.cuda.synchronize(dev)
+    scatter_choice = "narrow"
+    if not args.serial:  # the warm-up views' counters pick the scatter kernel (256- or 128-channel) for the timed ones
+        st_w = gsbp_amd.Engine.decode_stats(accum)
+        scatter_choice = pipe.choose_scatter_kernel(st_w["n_pairs"], st_w["n_headers"])
+    elif D % 256 == 0 and "GWBP_NO_WIDE" not in os.environ:
+        scatter_choice = "wide"  # serial schedule: the faster kernel alone, no priority games
+        eng.set_narrow_scatter(False)
     F.zero_()
     d.zero_()
     accum.zero_()
@@ -198,6 +205,8 @@ def main():
                 traffic = json.load(open(tfile)).get(args.config, {}).get("scatter_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        scatter_kernel = ("k_scatter_wide" if scatter_choice == "wide" else
+                          "k_scatter_full" if (D % 128 == 0 or D <= 64) else "k_scatter")
         out = {
             "metric": "Gaussian-pixel-features/sec", "value": total_pairs * D / elapsed,
             "unit": "Gaussian-pixel-features/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -213,7 +222,7 @@ def main():
                        "schedule": "serial" if args.serial else "front(v+1) overlapped with scatter(v) on two streams",
                        "stage_ms": {"front(project+sort+blend, side stream, overlapped)": t_front,
                                     "scatter": t_scatter}},
-            "roofline": {"bound": "hbm", "kernel": "k_scatter_full", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": scatter_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_scatter, "launch_ms": t_scatter,
                          "pipeline_achieved_GBs": b_view / (elapsed / args.steps) / 1e9,

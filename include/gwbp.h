@@ -65,6 +65,17 @@ typedef struct gwbp_caps {
  * pixel with alpha >= 1/255 (5 % + 1 px margin), so F, d, the weight store and every render are unchanged bit for bit;
  * only n_isect and the sorted intersection lists shrink.  Used by the fused back-projection path. */
 #define GWBP_FLAG_TIGHT_BINNING 1
+/* The kernels of gwbp_project / gwbp_bin_sort / gwbp_blend_weights run at raised wave priority.  For callers that run
+ * them on a second stream beside gwbp_scatter of the previous view when D % 256 == 0 (the 256-channel scatter kernel
+ * leaves issue slots the front can only use with priority; with the 128-channel kernel the flag costs time). */
+#define GWBP_FLAG_FRONT_PRIORITY 2
+/* gwbp_scatter uses the 128-channel kernel even when D % 256 == 0.  The 256-channel kernel needs fewer vector
+ * instructions per (pair, channel) but more work per (Gaussian, tile) record: it wins when records are long (C2: 48
+ * pairs per record, -5 % per view) and loses when they are short and the flush atomics dominate (C4: 25 pairs per
+ * record, +5 %).  The host decides from the first view's gwbp_stats (n_pairs / n_headers).  gwbp_blend_weights skips
+ * the half-tile record lists (15-20 % of its time) when the flag is set, so a view blended WITH the flag must be
+ * scattered with it; the other direction (blend without, scatter with) is fine. */
+#define GWBP_FLAG_NARROW_SCATTER 4
 
 /* Device-resident per-view counters, readable after the stream has drained (gwbp_read_stats). */
 typedef struct gwbp_stats {

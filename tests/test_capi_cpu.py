@@ -40,8 +40,9 @@ def test_workspace_size_and_argument_validation():
     caps = _lib.Caps(1_000_000, 16_000_000, 217_088_000, 1600, 1060)
     assert lib.gwbp_workspace_size(C.byref(caps), C.byref(n)) == 0
     # g2d 32 + rect 8 + touched 4 + depth-sort key/value ping-pong 16 B per Gaussian; tile key/value ping-pong 16 B +
-    # header 64 B per intersection; 8 B per weight-store entry
-    expect = 1_000_000 * 60 + 16_000_000 * 80 + 217_088_000 * 8
+    # header 64 B + two half-tile headers 16 B each per intersection; 8 B per weight-store entry; the carry slices of
+    # the 256-channel scatter (256 workgroups x 1024 rows x 1 KB)
+    expect = 1_000_000 * 60 + 16_000_000 * 112 + 217_088_000 * 8 + 256 * 1024 * 1024
     assert expect < n.value < expect * 1.02
     bad = _lib.Caps(-1, 16, 1 << 20, 64, 64)
     assert lib.gwbp_workspace_size(C.byref(bad), C.byref(n)) == -1

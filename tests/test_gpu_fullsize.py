@@ -75,3 +75,23 @@ def test_full_geometry_against_oracle(c2, dev, orc):
     assert st["n_pairs"] == info["n_pairs"] and st["n_isect"] == info["n_isect"] and st["n_visible"] == info["n_vis"]
     assert rel_row_err(F.cpu().numpy(), Fr) <= 1e-4
     assert rel_row_err(d.cpu().numpy()[:, None], dr[:, None]) <= 1e-4
+
+
+def test_wide_and_narrow_scatter_kernels_agree_at_full_size(c2, dev):
+    """C2 geometry, D = 256: the 256-channel kernel (half-tile slabs, carried partial sums, d through the headers'
+    weight sums) against the 128-channel kernel on the same view; both sum the same bit-identical weights."""
+    cfg, eng, g, vms, K = c2
+    D = 256
+    feats = syn.make_feature_map(cfg, 5, device=dev, dim=D)
+    out = {}
+    for name, narrow in (("narrow", True), ("wide", False)):
+        eng.set_narrow_scatter(narrow)
+        F, d, st = _run(eng, cfg, g, vms[1], K, feats, dev)
+        out[name] = (F, d, st)
+    eng.set_narrow_scatter(True)
+    assert out["wide"][2]["n_pairs"] == out["narrow"][2]["n_pairs"]
+    Fn, Fw = out["narrow"][0], out["wide"][0]
+    scale = float(Fn.norm(dim=1).max())
+    assert float((Fw - Fn).norm(dim=1).max()) <= 2e-5 * scale
+    dn, dw = out["narrow"][1], out["wide"][1]
+    assert float((dw - dn).abs().max()) <= 2e-5 * float(dn.max())

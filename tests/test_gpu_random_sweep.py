@@ -126,3 +126,44 @@ def test_scatter_grid_size_does_not_change_the_result(wgs, orc, dev):
                          feats.numpy(), Fr, dr)
     assert rel_row_err(F.cpu().numpy(), 2.0 * Fr) <= 1e-4
     assert rel_row_err(d.cpu().numpy()[:, None], 2.0 * dr[:, None]) <= 1e-4
+
+
+WIDE_CASES = [
+    # (seed, N, W, H, D, log_scale0): the 256-channel scatter kernel (half-tile slabs, carried partial sums)
+    (21, 2000, 130, 70, 256, 0.03),    # one chunk; records in one or both halves of a tile
+    (22, 64, 16, 16, 512, 0.50),       # one tile, screen-filling Gaussians: every record spans both halves, 128 entries per half
+    (23, 30000, 48, 48, 256, 0.02),    # > 1024 records per tile: the carry rows run out, the rest is flushed per half
+    (24, 1500, 96, 80, 768, 0.02),     # three chunks
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=[f"seed{c[0]}_N{c[1]}_{c[2]}x{c[3]}_D{c[4]}" for c in WIDE_CASES])
+def test_wide_scatter_kernel_matches_oracle_and_narrow(case, orc, dev):
+    seed, n, W, H, D, s0 = case
+    means, quats, scales, opac = _scene(seed, n, s0)
+    if seed == 23:  # faint Gaussians: nothing terminates, every tile collects thousands of records
+        opac = torch.full_like(opac, 0.03)
+    g_dev = [t.to(dev) for t in (means, quats, scales, opac)]
+    g_np = [t.numpy() for t in (means, quats, scales, opac)]
+    vm, K = _camera(seed, W, H)
+    feats = torch.randn(H, W, D, generator=torch.Generator().manual_seed(seed))
+    res = {}
+    for name, narrow in (("wide", False), ("narrow", True)):
+        eng = gsbp_amd.Engine(n, W, H, device=dev, pair_cap=1 << 25, isect_cap=1 << 22)
+        eng.set_narrow_scatter(narrow)
+        view = eng.view(vm, K, W, H)
+        F = torch.zeros(n, D, device=dev)
+        d = torch.zeros(n, device=dev)
+        eng.backproject_view(view, *g_dev, feats.to(dev), F, d)
+        eng.scatter(view, feats.to(dev), F, d)  # the same store again (queues re-armed, carry rows reused)
+        assert eng.stats()["overflow"] == 0
+        res[name] = (F.cpu().numpy(), d.cpu().numpy(), eng.stats())
+    Fr = np.zeros((n, D), np.float64)
+    dr = np.zeros(n, np.float64)
+    info = orc.backproject_view(*g_np, vm.numpy(), K.numpy(), W, H, feats.numpy(), Fr, dr)
+    assert res["wide"][2]["n_pairs"] == info["n_pairs"] == res["narrow"][2]["n_pairs"]
+    if seed == 23:
+        assert res["wide"][2]["n_headers"] > 2 * 1024 * 9  # 9 tiles, each well beyond the 1024 carry rows
+    for name in ("wide", "narrow"):
+        assert rel_row_err(res[name][0], 2.0 * Fr) <= 1e-4, name
+        assert rel_row_err(res[name][1][:, None], 2.0 * dr[:, None]) <= 1e-4, name
