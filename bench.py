@@ -95,6 +95,7 @@ def main():
             break
         eng.grow(st)
     if args.serial:
+        eng.set_narrow_scatter(not (D % 256 == 0 and "GWBP_NO_WIDE" not in os.environ))
         pipe, accum = None, torch.zeros(32, dtype=torch.uint8, device=dev)
     else:
         eng2 = gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap, tight_binning=tight)
@@ -145,8 +146,7 @@ def main():
         st_w = gsbp_amd.Engine.decode_stats(accum)
         scatter_choice = pipe.choose_scatter_kernel(st_w["n_pairs"], st_w["n_headers"])
     elif D % 256 == 0 and "GWBP_NO_WIDE" not in os.environ:
-        scatter_choice = "wide"  # serial schedule: the faster kernel alone, no priority games
-        eng.set_narrow_scatter(False)
+        scatter_choice = "wide"  # serial schedule: the faster kernel alone (set before the warm-up), no priority
     F.zero_()
     d.zero_()
     accum.zero_()

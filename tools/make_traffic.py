@@ -25,8 +25,8 @@ def kb(name, c):
     return avg.get(name, {}).get(c, 0.0) * 1024.0
 
 
-sc = next((k for k in avg if "k_scatter_full" in k), None)
-bl = next((k for k in avg if k.endswith("k_blend")), None)
+sc = next((k for k in avg if "k_scatter_wide" in k), None) or next((k for k in avg if "k_scatter_full" in k), None)
+bl = next((k for k in avg if "k_blend" in k), None)
 out = {
     "_about": "HBM traffic per launch from rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, TCC_* each in its own run with "
               "--kernel-trace only; tools/profile_round.sh), bench.py --steps 4 --warmup 1 --serial on C2, averaged over "
@@ -34,6 +34,7 @@ out = {
               "bytes of wide coalesced streaming reads -> doubled; WRITE_SIZE is exact for 16-B stores and float atomics. "
               "Counter unit is KB.",
     "C2": {
+        "scatter_kernel": sc,
         "scatter_hbm_bytes_per_launch": 2 * kb(sc, "FETCH_SIZE") + kb(sc, "WRITE_SIZE"),
         "scatter_fetch_bytes_corrected": 2 * kb(sc, "FETCH_SIZE"),
         "scatter_write_bytes": kb(sc, "WRITE_SIZE"),
