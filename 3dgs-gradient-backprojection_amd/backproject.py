@@ -110,12 +110,16 @@ class ViewPipeline:
         wide = (self.scatter_dim is not None and self.scatter_dim % 256 == 0 and "GWBP_NO_WIDE" not in os.environ)
         if wide and n_pairs is not None and n_headers:
             wide = n_pairs / n_headers >= self.WIDE_MIN_PAIRS_PER_RECORD
+        self.wide = wide
         for e in self.eng:
             e.set_narrow_scatter(not wide)
             e.set_front_priority(wide)
         return "wide" if wide else "narrow"
 
-    def front(self, view, means, quats, scales, opacities):
+    def front(self, view, means, quats, scales, opacities, d=None, scale_d=1.0):
+        """d (optional): the denominator accumulator.  With the 256-channel scatter kernel chosen, the view's share of d
+        is added right behind the blend on the side stream (gwbp_accumulate_d) and scatter() then leaves d alone: the
+        denominators cost nothing on the scatter's stream."""
         b = self.i_front % 2
         main = torch.cuda.current_stream(self.dev)
         if self.i_front < 2:
@@ -127,8 +131,11 @@ class ViewPipeline:
             e.project(view, means, quats, scales, opacities)
             e.bin_sort(view)
             e.blend_weights(view)
+            d_done = d is not None and self.wide
+            if d_done:
+                e.accumulate_d(view, d, scale_d)
             self.ev_front[b].record(self.side)
-        self.pending[self.i_front] = view
+        self.pending[self.i_front] = (view, d_done)
         self.i_front += 1
 
     def scatter(self, feats, F, d, scale_f=1.0, scale_d=1.0, t0=None, t1=None, upsample=None):
@@ -140,7 +147,8 @@ class ViewPipeline:
         e = self.eng[b]
         if t0 is not None:
             t0.record(main)
-        e.scatter(self.pending.pop(i), feats, F, d, scale_f, scale_d, upsample=upsample)
+        view, d_done = self.pending.pop(i)
+        e.scatter(view, feats, F, None if d_done else d, scale_f, scale_d, upsample=upsample)
         if t1 is not None:
             t1.record(main)
         e.accumulate_stats(self.accum)
@@ -196,13 +204,13 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                                                                             isect_cap=eng.isect_cap,
                                                                             pair_cap=eng.pair_cap)])
             views = [eng.view(vm_host[v], K_host, width, height) for v in my_views]
-            pipe.front(views[0], means, quats, scales, opacities)
+            pipe.front(views[0], means, quats, scales, opacities, d, sd)
             for i, v in enumerate(my_views):
                 if i == 2:  # one host sync per job: views 0 and 1 are counted, pick the scatter kernel for the rest
                     st01 = pipe.stats()
                     pipe.choose_scatter_kernel(st01["n_pairs"], st01["n_headers"])
                 if i + 1 < len(my_views):
-                    pipe.front(views[i + 1], means, quats, scales, opacities)
+                    pipe.front(views[i + 1], means, quats, scales, opacities, d, sd)
                 feats = feature_fn(v)
                 if encoder is not None:
                     feats = feats @ encoder

@@ -226,6 +226,22 @@ int gwbp_blend_weights(const gwbp_caps *caps, void *workspace, size_t workspace_
     return launch_blend(L, W, V, alphas, static_cast<hipStream_t>(stream));
 }
 
+int gwbp_accumulate_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                      float scale_d, float *d, void *stream)
+{
+    Layout L;
+    Ws W;
+    ViewDev V;
+    int rc = bind_workspace(caps, workspace, workspace_bytes, &L, &W);
+    if (rc)
+        return rc;
+    if ((rc = make_view(view_host, caps, &V)))
+        return rc;
+    if (!d)
+        return set_error(GWBP_EINVAL, "null d");
+    return launch_accum_d(L, W, V, scale_d, d, static_cast<hipStream_t>(stream));
+}
+
 static int scatter_impl(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                         const FeatMap &M, int32_t D, float scale_f, float scale_d, float *F, float *d, void *stream)
 {

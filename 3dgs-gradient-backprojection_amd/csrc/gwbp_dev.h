@@ -158,6 +158,7 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap
                    float scale_d, float *F, float *d, hipStream_t s);
 int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
                         float scale_d, float *F, float *d, hipStream_t s);
+int launch_accum_d(const Layout &L, const Ws &W, const ViewDev &V, float scale_d, float *d, hipStream_t s);
 int launch_scatter_wide(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
                         float *F, hipStream_t s);
 int launch_render(const Layout &L, const Ws &W, const ViewDev &V, const float *colors, int D, float *out,

@@ -254,6 +254,16 @@ __global__ __launch_bounds__(256) void k_accum_d(const u32 *__restrict__ tile_of
         atomicAdd(dsum_out + hb[h].gid, __int_as_float((int)hb[h].wsum) * scale_d);
 }
 
+int launch_accum_d(const Layout &L, const Ws &W, const ViewDev &V, float scale_d, float *d, hipStream_t s)
+{
+    if (L.flags & GWBP_FLAG_NARROW_SCATTER)
+        return set_error(GWBP_EINVAL, "gwbp_accumulate_d needs a blend without GWBP_FLAG_NARROW_SCATTER (no weight sums)");
+    const int n_tiles = V.tile_w * V.tile_h;
+    if (d && n_tiles > 0)
+        hipLaunchKernelGGL(k_accum_d, dim3(n_tiles), dim3(256), 0, s, W.tile_offsets, W.hdr_count, W.headers, scale_d, d);
+    return check_hip(hipGetLastError(), "accum_d launch");
+}
+
 int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
                    float scale_d, float *F, float *d, hipStream_t s)
 {
@@ -274,8 +284,11 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap
     // fast paths: D % 256 == 0 channel-contiguous (scatter_wide.hip); D % 128 == 0 or D <= 64, any strides (scatter_full.hip)
     static const bool no_wide = getenv("GWBP_NO_WIDE") != nullptr; // A/B knob
     if (D % 256 == 0 && M.fs_c == 1 && !no_wide && !(L.flags & GWBP_FLAG_NARROW_SCATTER)) {
-        if (d && n_tiles > 0)
-            hipLaunchKernelGGL(k_accum_d, dim3(n_tiles), dim3(256), 0, s, W.tile_offsets, W.hdr_count, W.headers, scale_d, d);
+        if (d) {
+            const int rc = launch_accum_d(L, W, V, scale_d, d, s);
+            if (rc)
+                return rc;
+        }
         return launch_scatter_wide(L, W, V, M, D, scale_f, F, s);
     }
     if (D % kChunk == 0 || D <= 64)

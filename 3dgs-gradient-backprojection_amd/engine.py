@@ -152,6 +152,13 @@ class Engine:
             raise GwbpError("negative feature-map strides are not supported")
         return sy, sx, sc, feats.shape[2]
 
+    def accumulate_d(self, view, d, scale_d=1.0):
+        """d += scale_d * sum_p w from the blend's per-record weight sums (needs a blend with the wide scatter enabled)."""
+        if d is None or d.dtype != torch.float32 or not d.is_cuda or d.shape != (self.n,) or not d.is_contiguous():
+            raise GwbpError("d must be a contiguous float32 HIP tensor [N]")
+        check(self.lib.gwbp_accumulate_d(*self._args(), C.byref(view), C.c_float(scale_d), ptr(d), self._stream()),
+              "gwbp_accumulate_d")
+
     def scatter(self, view, feats, F, d, scale_f=1.0, scale_d=1.0, upsample: Optional[str] = None):
         """F += scale_f * sum_p w feats[p], d += scale_d * sum_p w from the view's weight store.
 

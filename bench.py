@@ -112,7 +112,7 @@ def main():
             if 0 <= k < args.steps:
                 with torch.cuda.stream(pipe.side):
                     ev[k][0].record(pipe.side)
-            pipe.front(views[i], means, quats, scales, opac)
+            pipe.front(views[i], means, quats, scales, opac, d)  # d: added behind the blend when the wide kernel is used
             if 0 <= k < args.steps:
                 with torch.cuda.stream(pipe.side):
                     ev[k][1].record(pipe.side)

@@ -114,6 +114,13 @@ int gwbp_bin_sort(const gwbp_caps *caps, void *workspace, size_t workspace_bytes
 int gwbp_blend_weights(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                        float *alphas, void *stream);
 
+/* d[g] += scale_d * sum_p w_g(p) alone, from the per-record weight sums gwbp_blend_weights left in the workspace
+ * (needs a blend WITHOUT GWBP_FLAG_NARROW_SCATTER).  A caller that overlaps the front stage of view v+1 with the
+ * scatter of view v issues it behind the blend on the front's stream and passes d = NULL to gwbp_scatter: the
+ * denominators then cost nothing on the scatter's stream (backproject.py:133-150). */
+int gwbp_accumulate_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                      float scale_d, float *d, void *stream);
+
 /* What the reference obtains through backward(): F[g,:] += scale_f * sum_p w_g(p) * feats[p,:] and
  * d[g] += scale_d * sum_p w_g(p)   (backproject.py:127-131,145-150; scale = 1 for .sum(), 1/(H*W*D) and
  * 1/(H*W*3) for the dino .mean() variant, backproject.py:263,283).  feats is addressed as

@@ -455,3 +455,26 @@ def test_tight_binning_changes_only_the_lists(name, dev):
         assert s1["n_isect"] < s0["n_isect"]
         assert np.array_equal(k0, k1) and np.array_equal(w0.view(np.uint32), w1.view(np.uint32))
         assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
+
+
+@pytest.mark.parametrize("min_pairs", [0.0, 1e9], ids=["stay_wide", "switch_to_narrow"])
+def test_pipelined_driver_with_the_wide_scatter_kernel(dev, monkeypatch, min_pairs):
+    """D = 256: the pipeline starts on the 256-channel scatter kernel with d added behind the blend on the side stream,
+    then either keeps it or switches to the 128-channel kernel after two views (fronts already enqueued keep their own
+    d bookkeeping).  Must equal the serial driver (fused per-view call, 128-channel kernel)."""
+    monkeypatch.setattr(gsbp_amd.ViewPipeline, "WIDE_MIN_PAIRS_PER_RECORD", min_pairs)
+    cfg, sc = scene_np("T1", n_views=6)
+    d = to_dev(sc, dev)
+    D = 256
+    vms = syn.make_cameras(cfg, n_views=6).to(dev)
+    feats_all = [syn.make_feature_map(cfg, v, dim=D).to(dev) for v in range(6)]
+    res = []
+    for pipeline in (True, False):
+        out, F, dd, st = gsbp_amd.create_feature_field(d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"],
+                                                        cfg.width, cfg.height, lambda v: feats_all[v], D,
+                                                        pipeline=pipeline, return_partials=True)
+        res.append((F.cpu().numpy(), dd.cpu().numpy(), st["n_pairs"], out.cpu().numpy()))
+    assert res[0][2] == res[1][2]
+    assert rel_row_err(res[0][0], res[1][0]) <= 1e-5
+    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-5 * res[1][1].max()
+    assert rel_row_err(res[0][3], res[1][3]) <= 1e-5
