@@ -167,3 +167,33 @@ def test_wide_scatter_kernel_matches_oracle_and_narrow(case, orc, dev):
     for name in ("wide", "narrow"):
         assert rel_row_err(res[name][0], 2.0 * Fr) <= 1e-4, name
         assert rel_row_err(res[name][1][:, None], 2.0 * dr[:, None]) <= 1e-4, name
+
+
+def test_wide_scatter_kernel_with_nearest_upsampled_map(orc, dev):
+    """The 256-channel kernel reading a low-resolution map through the index maps (gwbp_scatter_upsampled, D = 256)."""
+    seed, n, W, H, D, s0 = 31, 2500, 150, 90, 256, 0.03
+    means, quats, scales, opac = _scene(seed, n, s0)
+    vm, K = _camera(seed, W, H)
+    low = torch.randn(11, 19, D, generator=torch.Generator().manual_seed(seed))
+    up = torch.nn.functional.interpolate(low.permute(2, 0, 1)[None], size=(H, W), mode="nearest")[0].permute(1, 2, 0)
+    eng = gsbp_amd.Engine(n, W, H, device=dev)
+    eng.set_narrow_scatter(False)
+    view = eng.view(vm, K, W, H)
+    eng.project(view, *[t.to(dev) for t in (means, quats, scales, opac)])
+    eng.bin_sort(view)
+    eng.blend_weights(view)
+    F = torch.zeros(n, D, device=dev)
+    d = torch.zeros(n, device=dev)
+    eng.scatter(view, low.to(dev), F, d, upsample="nearest")
+    d2 = torch.zeros(n, device=dev)
+    eng.accumulate_d(view, d2)  # the denominators alone, from the blend's weight sums
+    Fr = np.zeros((n, D), np.float64)
+    dr = np.zeros(n, np.float64)
+    orc.backproject_view(*[t.numpy() for t in (means, quats, scales, opac)], vm.numpy(), K.numpy(), W, H,
+                         np.ascontiguousarray(up.numpy()), Fr, dr)
+    assert rel_row_err(F.cpu().numpy(), Fr) <= 1e-4
+    assert rel_row_err(d.cpu().numpy()[:, None], dr[:, None]) <= 1e-4
+    assert torch.allclose(d, d2, rtol=1e-5, atol=0)
+    eng.set_narrow_scatter(True)
+    with pytest.raises(gsbp_amd.GwbpError):
+        eng.accumulate_d(view, d2)  # a narrow blend leaves no weight sums
