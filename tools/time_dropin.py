@@ -18,8 +18,10 @@ W, H, N = cfg.width, cfg.height, cfg.n_gaussians
 feats = syn.make_feature_map(cfg, 0, device=dev, dim=D)
 
 
-def sync_time(fn, n=3):
-    fn(); torch.cuda.synchronize()
+def sync_time(fn, n=5):
+    for _ in range(3):  # the caching allocator settles only after a few iterations of 3.5 GB temporaries
+        fn()
+    torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(n):
         fn()
