@@ -137,18 +137,19 @@ def test_render_forward_parity(orc, dev):
         assert np.abs(out - ref).max() <= 1e-5
 
 
-def test_reference_loop_through_dropin_shim(orc, dev):
+@pytest.mark.parametrize("D", [None, 256], ids=["D8", "D256_wide_scatter_in_backward"])
+def test_reference_loop_through_dropin_shim(orc, dev, D):
     """The literal loop of create_feature_field_lseg (backproject.py:62-72,115-151,166-169) with
     `rasterization` swapped for the drop-in -- zeros colours, .backward(), colors.grad harvest."""
     from gsbp_amd import rasterization
     cfg, sc = scene_np("T0")
     d, h = to_dev(sc, dev), npy(sc)
-    N, D = cfg.n_gaussians, cfg.feat_dim
+    N, D = cfg.n_gaussians, (D or cfg.feat_dim)
     gaussian_features = torch.zeros(N, D, device=dev)
     gaussian_denoms = torch.ones(N, device=dev) * 1e-12
     colors_feats = torch.zeros(N, D, device=dev, requires_grad=True)
     colors_feats_0 = torch.zeros(N, 3, device=dev, requires_grad=True)
-    feats_all = [syn.make_feature_map(cfg, v) for v in range(cfg.n_views)]
+    feats_all = [syn.make_feature_map(cfg, v, dim=D) for v in range(cfg.n_views)]
     for v in range(cfg.n_views):
         feats = feats_all[v].to(dev)
         out, _, meta = rasterization(d["means"], d["quats"], d["scales"], d["opac"], colors_feats, d["vms"][v][None],
