@@ -72,6 +72,40 @@ __device__ __forceinline__ void wait_e(EV (&e)[2])
                  : "memory");
 }
 
+// Small-D inner loop with SEVERAL pairs per wave-instruction: with D <= 32 channels a wave has room for P = 64 / Dp pairs
+// at once (Dp = D rounded up to 4, 8 or 16), lane = (pair slot, channel).  The slot's {w, pixel} comes from the
+// lane that holds the entry (ds_bpermute), so a step of P pairs costs 2 ds_bpermute + ds_read_b32 + v_fmac instead of
+// P x (2 v_readlane + address + ds_read_b32 + v_fmac).  The caller sums the P partial results of a channel afterwards.
+template <int LGD>
+__device__ __forceinline__ float packed_small_vec(const char *slab, u32 row_bytes, u32 cbase, int lane, float ev_w,
+                                                  u32 ev_pix, u32 n, float acc)
+{
+    constexpr int P = 64 >> LGD;                 // pairs per step
+    constexpr int kSteps = 64 / P;               // steps that cover one 64-entry vector
+    constexpr int SB = 4;                        // steps per batch (LDS operations in flight; 8 would cost the 64-VGPR budget of two workgroups per CU)
+    const int slot4 = (lane >> LGD) * 4;         // byte address of this lane's entry inside a step
+#pragma unroll 1
+    for (int t0 = 0; t0 < kSteps; t0 += SB) {
+        if ((u32)(P * t0) >= n) // wave-uniform; entries past n carry w = 0, so whole batches can go
+            break;
+        float wv[SB], fv[SB];
+        u32 pv[SB];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            const int addr = slot4 + 4 * P * (t0 + i); // entry P*(t0+i) + slot, always < 64
+            wv[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(ev_w)));
+            pv[i] = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)ev_pix);
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i)
+            fv[i] = *reinterpret_cast<const float *>(slab + (pv[i] * row_bytes + cbase));
+#pragma unroll
+        for (int i = 0; i < SB; ++i)
+            acc = __builtin_fmaf(wv[i], fv[i], acc);
+    }
+    return acc;
+}
+
 // SMALL = false: D % 128 == 0, 128-channel chunks, lanes = channel pairs (ds_read_b64 + v_pk_fma_f32).
 // SMALL = true : D <= 64 (C1 D = 32, C5 D = 16, the drop-in's 3-channel denominator pass), one chunk, lane l = channel l
 //                (ds_read_b32 + v_fmac), any feature-map strides, slab pitch = D rounded up to 4 floats.
@@ -189,7 +223,12 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
 
     const Header *hbase = headers + tile_offsets[tile];
     // byte offset of this lane's channel (pair) inside a pixel row; idle lanes of the small path re-read the last channel
-    const u32 lane_base = SMALL ? (u32)(min(lane, pitch - 1) * sizeof(float)) : (u32)(2 * lane * sizeof(float));
+    // small path: Dp = D rounded up to 4 / 8 / 16 / 32 / 64 channels per pair slot, lane = (slot, channel)
+    // (measured: D = 16 scatter 1.40 -> 1.24 ms at C5; two pairs per step at D = 32 were SLOWER than one -- the step is
+    // bound by its three LDS operations -- so 17..64 channels keep one pair per instruction)
+    const int lgd = !SMALL ? 6 : (D <= 4 ? 2 : D <= 8 ? 3 : D <= 16 ? 4 : 6);
+    const int chan = lane & ((1 << lgd) - 1);
+    const u32 lane_base = SMALL ? (u32)(min(chan, pitch - 1) * sizeof(float)) : (u32)(2 * lane * sizeof(float));
     const u32 row_bytes = (u32)pitch * (u32)sizeof(float);
     const char *slab = reinterpret_cast<const char *>(lds);
     const bool want_d = (chunk == 0) && (dsum_out != nullptr);
@@ -222,6 +261,16 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
     float2 acc = make_float2(0.f, 0.f);
     // n in 1..64 entries held by lanes 0..n-1 of ev (lanes >= n: w = 0, pix = any valid pixel)
     auto run_vec = [&](const EV &ev, u32 n) __attribute__((always_inline)) {
+        if constexpr (SMALL) {
+            if (lgd < 6) { // wave-uniform: several pairs per instruction
+                switch (lgd) {
+                case 2: acc.x = packed_small_vec<2>(slab, row_bytes, lane_base, lane, ev.w, ev.pix, n, acc.x); break;
+                case 3: acc.x = packed_small_vec<3>(slab, row_bytes, lane_base, lane, ev.w, ev.pix, n, acc.x); break;
+                default: acc.x = packed_small_vec<4>(slab, row_bytes, lane_base, lane, ev.w, ev.pix, n, acc.x); break;
+                }
+                return;
+            }
+        }
         // Batches of kB entries, two in flight: the next batch's LDS reads are issued before the current batch's FMAs.
         // Lane selects are compile-time constants; exits are wave-uniform.  Lists are padded to kB entries with {0, 0}.
         constexpr int kB = kListPad;
@@ -292,6 +341,8 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
         }
         float *Fg = F + (int64_t)R.gid * D + c0;
         if constexpr (SMALL) { // lane l = channel l: one atomic instruction (always issued, lanes >= D masked off)
+            for (int o = 1 << lgd; o < 64; o <<= 1) // packed pairs: add the slots' partial sums (wave-uniform trip count)
+                acc.x += __shfl_xor(acc.x, o, 64);
             if (lane < D) {
                 if (!(dbg & 1))
                     atomicAdd(Fg + lane, acc.x * scale_f);
