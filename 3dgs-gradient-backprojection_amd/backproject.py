@@ -42,8 +42,9 @@ def reduce_partials_sharded(F: torch.Tensor, d: torch.Tensor):
     Falls back to all-reduce + slice when N does not divide evenly or the backend has no reduce-scatter (gloo)."""
     dist, rank, world = _dist()
     n = F.shape[0]
-    if world == 1:
+    if dist is None:  # no process group: nothing to exchange
         return F, d, 0
+    # (a one-rank process group still goes through the collectives: `bench.py --force-dist` exercises the RCCL calls)
     per = -(-n // world)
     row0, row1 = min(rank * per, n), min((rank + 1) * per, n)
     dist.all_reduce(d, op=dist.ReduceOp.SUM)  # 4 B per Gaussian
