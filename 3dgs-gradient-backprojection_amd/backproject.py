@@ -198,43 +198,49 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     stats: Dict[str, int] = {}
     if view_fn is None:
         eng = engine or Engine(n, width, height, device=dev, tight_binning=True)  # same F and d, shorter tile lists
-        if pipeline and len(my_views) > 1:
-            pipe = ViewPipeline(n, width, height, dev, scatter_dim=d_out,
-                                engines=[eng, Engine(n, width, height, device=dev,
-                                                                            tight_binning=eng.tight_binning,
-                                                                            isect_cap=eng.isect_cap,
-                                                                            pair_cap=eng.pair_cap)])
-            views = [eng.view(vm_host[v], K_host, width, height) for v in my_views]
-            pipe.front(views[0], means, quats, scales, opacities, d, sd)
-            for i, v in enumerate(my_views):
-                if i == 2:  # one host sync per job: views 0 and 1 are counted, pick the scatter kernel for the rest
-                    st01 = pipe.stats()
-                    pipe.choose_scatter_kernel(st01["n_pairs"], st01["n_headers"])
-                if i + 1 < len(my_views):
-                    pipe.front(views[i + 1], means, quats, scales, opacities, d, sd)
-                feats = feature_fn(v)
-                if encoder is not None:
-                    feats = feats @ encoder
-                pipe.scatter(feats, F, d, sf, sd, upsample=upsample)
-            stats = pipe.stats()
-        else:
-            accum = torch.zeros(32, dtype=torch.uint8, device=dev)
-            for i, v in enumerate(my_views):
-                feats = feature_fn(v)
-                if encoder is not None:
-                    feats = feats @ encoder
-                view = eng.view(vm_host[v], K_host, width, height)
-                if upsample is None:
-                    eng.backproject_view(view, means, quats, scales, opacities, feats, F, d, sf, sd)
-                else:
-                    eng.project(view, means, quats, scales, opacities)
-                    eng.bin_sort(view)
-                    eng.blend_weights(view)
-                    eng.scatter(view, feats, F, d, sf, sd, upsample=upsample)
-                eng.accumulate_stats(accum)
-            stats = Engine.decode_stats(accum)  # synchronises
-        if stats["overflow"]:
-            raise RuntimeError(f"workspace overflow (flags {stats['overflow']}): enlarge isect_cap/pair_cap and rerun")
+        for attempt in range(6):  # a capacity overflow invalidates the accumulators: grow the workspace, start over
+            if pipeline and len(my_views) > 1:
+                pipe = ViewPipeline(n, width, height, dev, scatter_dim=d_out,
+                                    engines=[eng, Engine(n, width, height, device=dev,
+                                                                                tight_binning=eng.tight_binning,
+                                                                                isect_cap=eng.isect_cap,
+                                                                                pair_cap=eng.pair_cap)])
+                views = [eng.view(vm_host[v], K_host, width, height) for v in my_views]
+                pipe.front(views[0], means, quats, scales, opacities, d, sd)
+                for i, v in enumerate(my_views):
+                    if i == 2:  # one host sync per job: views 0 and 1 are counted, pick the scatter kernel for the rest
+                        st01 = pipe.stats()
+                        pipe.choose_scatter_kernel(st01["n_pairs"], st01["n_headers"])
+                    if i + 1 < len(my_views):
+                        pipe.front(views[i + 1], means, quats, scales, opacities, d, sd)
+                    feats = feature_fn(v)
+                    if encoder is not None:
+                        feats = feats @ encoder
+                    pipe.scatter(feats, F, d, sf, sd, upsample=upsample)
+                stats = pipe.stats()
+            else:
+                accum = torch.zeros(32, dtype=torch.uint8, device=dev)
+                for i, v in enumerate(my_views):
+                    feats = feature_fn(v)
+                    if encoder is not None:
+                        feats = feats @ encoder
+                    view = eng.view(vm_host[v], K_host, width, height)
+                    if upsample is None:
+                        eng.backproject_view(view, means, quats, scales, opacities, feats, F, d, sf, sd)
+                    else:
+                        eng.project(view, means, quats, scales, opacities)
+                        eng.bin_sort(view)
+                        eng.blend_weights(view)
+                        eng.scatter(view, feats, F, d, sf, sd, upsample=upsample)
+                    eng.accumulate_stats(accum)
+                stats = Engine.decode_stats(accum)  # synchronises
+            if not stats["overflow"]:
+                break
+            if attempt == 5:
+                raise RuntimeError(f"workspace overflow (flags {stats['overflow']}) after five enlargements")
+            eng.grow(stats, views=len(my_views))
+            F.zero_()
+            d.zero_()
     else:
         eng = None
         for v in my_views:

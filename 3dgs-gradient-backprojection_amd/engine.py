@@ -87,12 +87,14 @@ class Engine:
         off = (-self.ws.data_ptr()) % 256
         self._ws_ptr = C.c_void_p(self.ws.data_ptr() + off)
 
-    def grow(self, stats: Dict[str, int]):
-        """Enlarge whichever capacity overflowed (bit0 = isect, bit1 = pairs) and reallocate."""
+    def grow(self, stats: Dict[str, int], views: int = 1):
+        """Enlarge whichever capacity overflowed (bit0 = isect, bit1 = pairs) and reallocate.  The pair counter keeps
+        counting after the pool is exhausted, so the weight store can be sized for what the views really needed
+        (`stats` summed over `views` views)."""
         if stats["overflow"] & 1:
             self.isect_cap *= 2
         if stats["overflow"] & 2:
-            self.pair_cap *= 2
+            self.pair_cap = max(2 * self.pair_cap, int(2.5 * stats["n_pairs"] / max(1, views)) + (1 << 16))
         del self.ws
         self._alloc()
 

@@ -479,3 +479,22 @@ def test_pipelined_driver_with_the_wide_scatter_kernel(dev, monkeypatch, min_pai
     assert rel_row_err(res[0][0], res[1][0]) <= 1e-5
     assert np.abs(res[0][1] - res[1][1]).max() <= 1e-5 * res[1][1].max()
     assert rel_row_err(res[0][3], res[1][3]) <= 1e-5
+
+
+@pytest.mark.parametrize("pipeline", [True, False], ids=["pipelined", "serial"])
+def test_driver_grows_the_workspace_on_overflow(dev, pipeline):
+    """Capacities far too small for the scene: the driver notices the overflow flags at the end of the pass, enlarges
+    the workspace and starts over; the result must equal the run with ample capacities."""
+    cfg, sc = scene_np("T1", n_views=4)
+    d = to_dev(sc, dev)
+    vms = syn.make_cameras(cfg, n_views=4).to(dev)
+    feats_all = [syn.make_feature_map(cfg, v).to(dev) for v in range(4)]
+    args = (d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"], cfg.width, cfg.height, lambda v: feats_all[v],
+            cfg.feat_dim)
+    small = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, isect_cap=3000, pair_cap=1 << 15,
+                            tight_binning=True)
+    a, Fa, da, st = gsbp_amd.create_feature_field(*args, engine=small, pipeline=pipeline, return_partials=True)
+    assert small.isect_cap > 3000 and st["overflow"] == 0
+    b, Fb, db, _ = gsbp_amd.create_feature_field(*args, pipeline=pipeline, return_partials=True)
+    assert rel_row_err(Fa.cpu().numpy(), Fb.cpu().numpy()) <= 1e-5
+    assert np.abs(da.cpu().numpy() - db.cpu().numpy()).max() <= 1e-5 * float(db.max())
