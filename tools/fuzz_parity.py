@@ -1,0 +1,76 @@
+"""Randomised parity fuzz (GPU + oracle): many small random scenes, image sizes, channel counts, map layouts and both
+D % 256 == 0 scatter kernels against the CPU oracle.  Not part of the test suite (minutes of run time).
+  python tools/fuzz_parity.py [n_cases] [seed0]"""
+import math
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import gsbp_amd  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from util import rel_row_err  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dev = torch.device("cuda:0")
+orc.build()
+DIMS = [1, 3, 4, 7, 8, 12, 16, 17, 32, 40, 64, 65, 100, 128, 130, 256, 384, 512, 768]
+bad = 0
+t0 = time.time()
+for case in range(n_cases):
+    rng = np.random.default_rng(seed0 + case)
+    n = int(rng.integers(1, 4000))
+    W, H = int(rng.integers(1, 260)), int(rng.integers(1, 200))
+    D = int(rng.choice(DIMS))
+    s0 = float(10 ** rng.uniform(-2.6, -0.3))
+    g = torch.Generator().manual_seed(seed0 + case)
+    means = (torch.rand(n, 3, generator=g) * 2 - 1) * float(rng.uniform(0.2, 1.5))
+    scales = torch.exp(math.log(s0) + 0.8 * torch.randn(n, 3, generator=g))
+    quats = torch.randn(n, 4, generator=g)
+    opac = torch.sigmoid(float(rng.uniform(0.5, 3.0)) * torch.randn(n, generator=g) + float(rng.uniform(-3, 2)))
+    th, el, r = float(rng.uniform(0, 2 * math.pi)), math.radians(float(rng.uniform(5, 70))), float(rng.uniform(1.2, 5))
+    c = torch.tensor([r * math.cos(th) * math.cos(el), r * math.sin(th) * math.cos(el), r * math.sin(el)])
+    fwd = -c / c.norm()
+    right = torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0]))
+    right = right / right.norm()
+    R = torch.stack([right, torch.linalg.cross(fwd, right), fwd])
+    vm = torch.eye(4)
+    vm[:3, :3], vm[:3, 3] = R, -R @ c
+    f = float(rng.uniform(0.5, 2.0)) * max(W, H)
+    K = torch.tensor([[f, 0, W / 2 + float(rng.uniform(-3, 3))], [0, f * float(rng.uniform(0.8, 1.2)), H / 2], [0, 0, 1.0]])
+    feats = torch.randn(H, W, D, generator=g)
+    if D < 4:
+        feats = feats.abs()
+    layout = rng.choice(["hwc", "chw", "pad"])
+    fd = feats.to(dev)
+    if layout == "chw":
+        fd = fd.permute(2, 0, 1).contiguous().permute(1, 2, 0)
+    elif layout == "pad":
+        buf = torch.zeros(H, W + 2, D + 4, device=dev)
+        buf[:, :W, :D] = fd
+        fd = buf[:, :W, :D]
+    wide = bool(rng.integers(0, 2))
+    tight = bool(rng.integers(0, 2))
+    eng = gsbp_amd.Engine(n, W, H, device=dev, tight_binning=tight, isect_cap=1 << 21, pair_cap=1 << 24)
+    eng.set_narrow_scatter(not wide)
+    F = torch.zeros(n, D, device=dev)
+    d = torch.zeros(n, device=dev)
+    eng.backproject_view(eng.view(vm, K, W, H), means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev), fd, F, d)
+    st = eng.stats()
+    Fr, dr = np.zeros((n, D), np.float64), np.zeros(n, np.float64)
+    info = orc.backproject_view(means.numpy(), quats.numpy(), scales.numpy(), opac.numpy(), vm.numpy(), K.numpy(), W, H,
+                                feats.numpy(), Fr, dr)
+    ok = st["overflow"] == 0 and st["n_pairs"] == info["n_pairs"] and st["n_visible"] == info["n_vis"]
+    eF = rel_row_err(F.cpu().numpy(), Fr) if info["n_pairs"] else 0.0
+    ed = rel_row_err(d.cpu().numpy()[:, None], dr[:, None]) if info["n_pairs"] else 0.0
+    ok = ok and eF <= 1e-4 and ed <= 1e-4 and (tight or st["n_isect"] == info["n_isect"])
+    if not ok:
+        bad += 1
+        print(f"FAIL case {seed0 + case}: N={n} {W}x{H} D={D} s0={s0:.4f} {layout} wide={wide} tight={tight} "
+              f"pairs {st['n_pairs']}/{info['n_pairs']} eF={eF:.2e} ed={ed:.2e} overflow={st['overflow']}", flush=True)
+print(f"{n_cases} cases, {bad} failures, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
