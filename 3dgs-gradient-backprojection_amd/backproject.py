@@ -172,9 +172,10 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     LSeg/DINO forward of backproject.py:102-113 / :236-249).
     reduction: "sum" (lseg, backproject.py:127,145) or "mean" (dino, backproject.py:263,283).
     encoder [dim, dim_out]: backproject_compressed.py:127 (feats @ encoder before back-projection).
-    upsample="nearest": feature_fn returns the network's LOW-RESOLUTION map [h,w,dim] (dino patch tokens,
-    backproject.py:242-243); the nearest upsampling to (height, width) of backproject.py:244-248 happens inside the
-    scatter kernel's addressing instead of materialising an [H,W,dim] map per view.
+    upsample="nearest" | "bilinear": feature_fn returns the network's LOW-RESOLUTION map [h,w,dim] (dino patch tokens,
+    backproject.py:242-243; the normalised lseg map, :108-109); the upsampling to (height, width) of
+    backproject.py:244-248 / :110-112 happens while the scatter kernel stages its tile slabs instead of materialising
+    an [H,W,dim] map per view.
     views: explicit list of view indices for this rank (default: interleaved shard over the process group).
     view_fn: injection point for the per-view accumulate (tests drive the sharding/reduction logic on CPU).
     pipeline: overlap the front stages of view v+1 with the scatter of view v (ViewPipeline).

@@ -264,7 +264,7 @@ int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
                  const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c, int32_t D, float scale_f,
                  float scale_d, float *F, float *d, void *stream)
 {
-    const FeatMap M{feats, fs_y, fs_x, fs_c, nullptr, nullptr};
+    const FeatMap M{feats, fs_y, fs_x, fs_c, nullptr, nullptr, nullptr, nullptr, 0, 0};
     return scatter_impl(caps, workspace, workspace_bytes, view_host, M, D, scale_f, scale_d, F, d, stream);
 }
 
@@ -275,7 +275,18 @@ int gwbp_scatter_upsampled(const gwbp_caps *caps, void *workspace, size_t worksp
 {
     if (!ymap || !xmap)
         return set_error(GWBP_EINVAL, "gwbp_scatter_upsampled needs both index maps");
-    const FeatMap M{feats, fs_y, fs_x, fs_c, ymap, xmap};
+    const FeatMap M{feats, fs_y, fs_x, fs_c, ymap, xmap, nullptr, nullptr, 0, 0};
+    return scatter_impl(caps, workspace, workspace_bytes, view_host, M, D, scale_f, scale_d, F, d, stream);
+}
+
+int gwbp_scatter_bilinear(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                          const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c, int32_t D, int32_t lr_h,
+                          int32_t lr_w, const int32_t *y0, const float *ly, const int32_t *x0, const float *lx,
+                          float scale_f, float scale_d, float *F, float *d, void *stream)
+{
+    if (!y0 || !x0 || !ly || !lx || lr_h < 1 || lr_w < 1)
+        return set_error(GWBP_EINVAL, "gwbp_scatter_bilinear needs both index maps, both weight maps and the map size");
+    const FeatMap M{feats, fs_y, fs_x, fs_c, y0, x0, ly, lx, lr_h, lr_w};
     return scatter_impl(caps, workspace, workspace_bytes, view_host, M, D, scale_f, scale_d, F, d, stream);
 }
 
@@ -348,7 +359,7 @@ int gwbp_backproject_view(const gwbp_caps *caps, void *workspace, size_t workspa
         return rc;
     if ((rc = launch_blend(L, W, V, nullptr, s)))
         return rc;
-    const FeatMap M{feats, fs_y, fs_x, fs_c, nullptr, nullptr};
+    const FeatMap M{feats, fs_y, fs_x, fs_c, nullptr, nullptr, nullptr, nullptr, 0, 0};
     return launch_scatter(L, W, V, M, D, scale_f, scale_d, F, d, s);
 }
 

@@ -143,15 +143,32 @@ int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *ise
 int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, hipStream_t s);
 // A 2-D feature map as the scatter kernels address it: feats[row(y)*fs_y + col(x)*fs_x + c*fs_c] (strides in floats).
 // ymap/xmap (device, optional) send an output pixel to the row/column of a lower-resolution map: the
-// F.interpolate(mode="nearest") of backproject.py:244-248 without materialising the upsampled map.
+// F.interpolate(mode="nearest") of backproject.py:244-248 without materialising the upsampled map.  With ly/lx as well
+// the map is sampled BILINEARLY (backproject.py:110-112, align_corners=False): ymap/xmap hold the lower texel, ly/lx
+// the weight of the upper one, lr_h/lr_w clamp the upper texel; ATen's operation order is kept.
 struct FeatMap {
     const float *p;
     int64_t fs_y, fs_x, fs_c;
     const int32_t *ymap, *xmap;
+    const float *ly, *lx;
+    int32_t lr_h, lr_w;
     __host__ __device__ __forceinline__ int64_t pixel(int iy, int ix) const
     {
         const int64_t yy = ymap ? ymap[iy] : iy, xx = xmap ? xmap[ix] : ix;
         return yy * fs_y + xx * fs_x;
+    }
+    __host__ __device__ __forceinline__ bool bilinear() const { return ly != nullptr; }
+    // one channel of one pixel; chan = p + c * fs_c
+    __device__ __forceinline__ float sample(const float *chan, int iy, int ix) const
+    {
+        if (!bilinear())
+            return chan[pixel(iy, ix)];
+        const int y0 = ymap[iy], x0 = xmap[ix];
+        const int y1 = min(y0 + 1, lr_h - 1), x1 = min(x0 + 1, lr_w - 1);
+        const float h1 = ly[iy], w1 = lx[ix], h0 = 1.0f - h1, w0 = 1.0f - w1;
+        const float a = chan[y0 * fs_y + x0 * fs_x], b = chan[y0 * fs_y + x1 * fs_x];
+        const float c = chan[y1 * fs_y + x0 * fs_x], d = chan[y1 * fs_y + x1 * fs_x];
+        return h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d); // UpSampleBilinear2d: same association
     }
 };
 int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,

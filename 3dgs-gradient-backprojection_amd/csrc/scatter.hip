@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_scatter(
         *s_next = 0;
 
     // ---- stage the feature slab -------------------------------------------------------------------------
-    const bool vec_ok = (fs_c == 1) && ((pitch & 3) == 0) && ((cw & 3) == 0) && ((fs_x & 3) == 0) &&
+    const bool vec_ok = !M.bilinear() && (fs_c == 1) && ((pitch & 3) == 0) && ((cw & 3) == 0) && ((fs_x & 3) == 0) &&
                         ((fs_y & 3) == 0) && ((c0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(feats) & 15) == 0);
     if (vec_ok) {
         const int vpr = pitch >> 2; // float4 per pixel row
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_scatter(
             const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
             float val = 0.f;
             if (ix < V.W && iy < V.H && c < cw)
-                val = feats[M.pixel(iy, ix) + (int64_t)(c0 + c) * fs_c];
+                val = M.sample(feats + (int64_t)(c0 + c) * fs_c, iy, ix);
             lds[p * pitch + c] = val;
         }
     }
@@ -283,7 +283,7 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap
     }
     // fast paths: D % 256 == 0 channel-contiguous (scatter_wide.hip); D % 128 == 0 or D <= 64, any strides (scatter_full.hip)
     static const bool no_wide = getenv("GWBP_NO_WIDE") != nullptr; // A/B knob
-    if (D % 256 == 0 && M.fs_c == 1 && !no_wide && !(L.flags & GWBP_FLAG_NARROW_SCATTER)) {
+    if (D % 256 == 0 && M.fs_c == 1 && !M.bilinear() && !no_wide && !(L.flags & GWBP_FLAG_NARROW_SCATTER)) {
         if (d) {
             const int rc = launch_accum_d(L, W, V, scale_d, d, s);
             if (rc)

@@ -109,10 +109,10 @@ __device__ __forceinline__ float packed_small_vec(const char *slab, u32 row_byte
 // SMALL = false: D % 128 == 0, 128-channel chunks, lanes = channel pairs (ds_read_b64 + v_pk_fma_f32).
 // SMALL = true : D <= 64 (C1 D = 32, C5 D = 16, the drop-in's 3-channel denominator pass), one chunk, lane l = channel l
 //                (ds_read_b32 + v_fmac), any feature-map strides, slab pitch = D rounded up to 4 floats.
-template <bool SMALL>
+template <bool SMALL, int VEC> // VEC (slab staging): 1 = 16-B loads, 2 = 16-B loads + bilinear blend, 0 = element-wise
 __global__ __launch_bounds__(kThreads) void k_scatter_full(
     ViewDev V, int n_chunks, const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
-    const Header *__restrict__ headers, const WPair *__restrict__ wpool, FeatMap M, int vec_ok, int pitch_rt, int D,
+    const Header *__restrict__ headers, const WPair *__restrict__ wpool, FeatMap M, int pitch_rt, int D,
     float scale_f, float scale_d, float *__restrict__ F, float *__restrict__ dsum_out, u32 *__restrict__ queues,
     int dbg)
 {
@@ -162,10 +162,35 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
                 const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
                 float val = 0.f;
                 if (ix < V.W && iy < V.H && c < D)
-                    val = feats[M.pixel(iy, ix) + (int64_t)c * fs_c];
+                    val = M.sample(feats + (int64_t)c * fs_c, iy, ix);
                 lds[idx] = val;
             }
-        } else if (!vec_ok) {
+        } else if constexpr (VEC == 2) {
+            // bilinear low-resolution map, channel-contiguous: every float4 of the slab is the blend of four float4
+            // (L2/MALL-resident texels); one unit per round: four 16-B loads in flight per thread, 16 registers
+            constexpr int vpr = kChunk >> 2;
+            constexpr int kIt = kTilePix * vpr / kThreads; // 8
+#pragma unroll 1
+            for (int it = 0; it < kIt; ++it) {
+                const int idx = it * kThreads + threadIdx.x;
+                const int p = idx / vpr, v = idx - p * vpr;
+                const int ix = min(tx * kTile + (p & 15), V.W - 1), iy = min(ty * kTile + (p >> 4), V.H - 1);
+                const int y0 = M.ymap[iy], x0 = M.xmap[ix];
+                const int y1 = min(y0 + 1, M.lr_h - 1), x1 = min(x0 + 1, M.lr_w - 1);
+                const float h1 = M.ly[iy], w1 = M.lx[ix], h0 = 1.0f - h1, w0 = 1.0f - w1;
+                const float *b0 = feats + c0 + 4 * v;
+                const float4 qa = *reinterpret_cast<const float4 *>(b0 + y0 * M.fs_y + x0 * M.fs_x);
+                const float4 qb = *reinterpret_cast<const float4 *>(b0 + y0 * M.fs_y + x1 * M.fs_x);
+                const float4 qc = *reinterpret_cast<const float4 *>(b0 + y1 * M.fs_y + x0 * M.fs_x);
+                const float4 qd = *reinterpret_cast<const float4 *>(b0 + y1 * M.fs_y + x1 * M.fs_x);
+                float4 r;
+                r.x = h0 * (w0 * qa.x + w1 * qb.x) + h1 * (w0 * qc.x + w1 * qd.x);
+                r.y = h0 * (w0 * qa.y + w1 * qb.y) + h1 * (w0 * qc.y + w1 * qd.y);
+                r.z = h0 * (w0 * qa.z + w1 * qb.z) + h1 * (w0 * qc.z + w1 * qd.z);
+                r.w = h0 * (w0 * qa.w + w1 * qb.w) + h1 * (w0 * qc.w + w1 * qd.w);
+                *reinterpret_cast<float4 *>(lds + p * kChunk + 4 * v) = r;
+            }
+        } else if constexpr (VEC == 0) {
             // any strides (e.g. the channel-major [D,H,W] map that permute(1,2,0) of backproject.py:249 hands over):
             // lane = 8 pixels of a tile row x 8 channels -> 32-B runs of a channel plane on the load side, a 4-way
             // bank conflict (2x a ds_write_b32) on the LDS side; 32 dwords per thread, eight in flight
@@ -180,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
                     const int p = (u & 31) * 8 + pl, c = (u >> 5) * 8 + cl;
                     const int ix = tx * kTile + (p & 15), iy = ty * kTile + (p >> 4);
                     const int cx_ = min(ix, V.W - 1), cy_ = min(iy, V.H - 1);
-                    vals[j] = feats[M.pixel(cy_, cx_) + (int64_t)(c0 + c) * fs_c];
+                    vals[j] = M.sample(feats + (int64_t)(c0 + c) * fs_c, cy_, cx_);
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
                     lds[p * kChunk + c] = vals[j];
                 }
             }
-        } else { // stage the 256 px x 128 ch slab: 32 float4 per pixel row
+        } else { // vec_ok == 1: stage the 256 px x 128 ch slab, 32 float4 per pixel row
             constexpr int vpr = kChunk >> 2;
             constexpr int kIt = kTilePix * vpr / kThreads; // 8
             float4 vals[kIt];
@@ -441,23 +466,25 @@ int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const Fe
 {
     const bool small = D <= 64;
     // 16-B vector staging needs channel-contiguous, 16-B aligned pixel rows
-    const int vec_ok = M.fs_c == 1 && (M.fs_x % 4 == 0) && (M.fs_y % 4 == 0) &&
-                       ((reinterpret_cast<uintptr_t>(M.p) & 15) == 0);
+    const bool aligned = M.fs_c == 1 && (M.fs_x % 4 == 0) && (M.fs_y % 4 == 0) &&
+                         ((reinterpret_cast<uintptr_t>(M.p) & 15) == 0);
+    const int vec_ok = aligned ? (M.bilinear() ? 2 : 1) : 0; // 1: 16-B staging, 2: 16-B bilinear staging, 0: element-wise
     const int n_chunks = small ? 1 : D / kChunk;
     const int pitch = small ? ((D + 3) & ~3) : kChunk;
     const size_t lds_bytes = (size_t)kTilePix * pitch * sizeof(float) + 16; // slab + work counter + two item slots
     static bool attr_done = false; // benign race: idempotent
     if (!attr_done) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_full<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes),
-                           "scatter_full LDS attribute");
-        if (rc)
-            return rc;
-        rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_full<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16),
-                       "scatter_small LDS attribute");
-        if (rc)
-            return rc;
+        const void *fns[4] = {reinterpret_cast<const void *>(k_scatter_full<false, 0>),
+                              reinterpret_cast<const void *>(k_scatter_full<false, 1>),
+                              reinterpret_cast<const void *>(k_scatter_full<false, 2>),
+                              reinterpret_cast<const void *>(k_scatter_full<true, 0>)};
+        for (int i = 0; i < 4; ++i) {
+            const int rc = check_hip(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         i < 3 ? (int)kLdsBytes : 65536 + 16),
+                                     "scatter_full LDS attribute");
+            if (rc)
+                return rc;
+        }
         attr_done = true;
     }
     static const char *ab = getenv("GWBP_ABLATE"); // profiling ablation only, read once (results are invalid when set)
@@ -474,14 +501,19 @@ int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const Fe
     int grid = L.scatter_wgs > 0 ? L.scatter_wgs : (small ? 2 * n_cu : n_cu);
     grid = (grid + 7) & ~7;
     u32 *queues = W.shards + kShards * 16;
+    const int dbg = ab ? atoi(ab) : 0;
+#define GWBP_LAUNCH(S, Vc)                                                                                            \
+    hipLaunchKernelGGL((k_scatter_full<S, Vc>), dim3(grid), dim3(kThreads), lds_bytes, s, V, n_chunks, W.tile_offsets,  \
+                       W.hdr_count, W.headers, W.wpool, M, pitch, D, scale_f, scale_d, F, d, queues, dbg)
     if (small)
-        hipLaunchKernelGGL(k_scatter_full<true>, dim3(grid), dim3(kThreads), lds_bytes, s, V, n_chunks, W.tile_offsets,
-                           W.hdr_count, W.headers, W.wpool, M, vec_ok, pitch, D, scale_f, scale_d, F, d, queues,
-                           ab ? atoi(ab) : 0);
+        GWBP_LAUNCH(true, 0);
+    else if (vec_ok == 1)
+        GWBP_LAUNCH(false, 1);
+    else if (vec_ok == 2)
+        GWBP_LAUNCH(false, 2);
     else
-        hipLaunchKernelGGL(k_scatter_full<false>, dim3(grid), dim3(kThreads), lds_bytes, s, V, n_chunks,
-                           W.tile_offsets, W.hdr_count, W.headers, W.wpool, M, vec_ok, pitch, D, scale_f, scale_d, F, d,
-                           queues, ab ? atoi(ab) : 0);
+        GWBP_LAUNCH(false, 0);
+#undef GWBP_LAUNCH
     return check_hip(hipGetLastError(), "scatter_full launch");
 }
 

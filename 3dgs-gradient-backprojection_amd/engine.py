@@ -27,6 +27,20 @@ def nearest_index(n_in: int, n_out: int) -> torch.Tensor:
     return idx.to(torch.int32)
 
 
+def bilinear_index(n_in: int, n_out: int):
+    """(lower source index int32[n_out], weight of the upper neighbour float32[n_out]) of
+    torch.nn.functional.interpolate(mode="bilinear", align_corners=False), computed like ATen's
+    area_pixel_compute_source_index in fp32: src = max(scale * (dst + 0.5) - 0.5, 0), scale = n_in / n_out
+    (the op the reference applies at backproject.py:110-112)."""
+    if n_in < 1 or n_out < 1:
+        raise ValueError("sizes must be positive")
+    scale = torch.tensor(float(n_in), dtype=torch.float32) / torch.tensor(float(n_out), dtype=torch.float32)
+    src = (scale * (torch.arange(n_out, dtype=torch.float32) + 0.5) - 0.5).clamp_(min=0.0)
+    i0 = src.to(torch.int64).clamp_(max=n_in - 1)
+    lam = (src - i0.to(torch.float32)).clamp_(0.0, 1.0)
+    return i0.to(torch.int32), lam
+
+
 def _req(t: torch.Tensor, name: str, shape_tail=None) -> torch.Tensor:
     if not t.is_cuda:
         raise GwbpError(f"{name} must be a CUDA/HIP tensor (no CPU fallback exists for this path)")
@@ -164,8 +178,9 @@ class Engine:
     def scatter(self, view, feats, F, d, scale_f=1.0, scale_d=1.0, upsample: Optional[str] = None):
         """F += scale_f * sum_p w feats[p], d += scale_d * sum_p w from the view's weight store.
 
-        upsample="nearest": feats is a LOW-RESOLUTION map [h,w,D]; the result equals scattering
-        F.interpolate(feats, size=(H,W), mode="nearest") (backproject.py:244-248) without building that map."""
+        upsample="nearest" / "bilinear": feats is a LOW-RESOLUTION map [h,w,D]; the result equals scattering
+        F.interpolate(feats, size=(H,W), mode=...) (dino: backproject.py:244-248; lseg: backproject.py:110-112,
+        align_corners=False) without building that map -- the interpolation happens while the tile slabs are staged."""
         if upsample is None:
             sy, sx, sc, D = self._feat_strides(feats, view)
             self._check_acc(F, d, D)
@@ -173,15 +188,33 @@ class Engine:
                                         C.c_int64(sc), D, C.c_float(scale_f), C.c_float(scale_d), ptr(F), ptr(d),
                                         self._stream()), "gwbp_scatter")
             return
-        if upsample != "nearest":
-            raise GwbpError(f"upsample must be None or 'nearest', got {upsample!r}")
+        if upsample not in ("nearest", "bilinear"):
+            raise GwbpError(f"upsample must be None, 'nearest' or 'bilinear', got {upsample!r}")
         sy, sx, sc, D = self._feat_strides(feats, view, lowres=True)
         self._check_acc(F, d, D)
+        if upsample == "bilinear":
+            y0, ly, x0, lx = self.bilinear_maps(feats.shape[0], feats.shape[1], view.height, view.width)
+            check(self.lib.gwbp_scatter_bilinear(*self._args(), C.byref(view), ptr(feats), C.c_int64(sy),
+                                                 C.c_int64(sx), C.c_int64(sc), D, int(feats.shape[0]),
+                                                 int(feats.shape[1]), ptr(y0), ptr(ly), ptr(x0), ptr(lx),
+                                                 C.c_float(scale_f), C.c_float(scale_d), ptr(F), ptr(d),
+                                                 self._stream()), "gwbp_scatter_bilinear")
+            return
         ymap, xmap = self.nearest_maps(feats.shape[0], feats.shape[1], view.height, view.width)
         check(self.lib.gwbp_scatter_upsampled(*self._args(), C.byref(view), ptr(feats), C.c_int64(sy), C.c_int64(sx),
                                               C.c_int64(sc), D, ptr(ymap), ptr(xmap), C.c_float(scale_f),
                                               C.c_float(scale_d), ptr(F), ptr(d), self._stream()),
               "gwbp_scatter_upsampled")
+
+    def bilinear_maps(self, h: int, w: int, H: int, W: int):
+        """device maps of F.interpolate(mode="bilinear", align_corners=False): (y0[H], ly[H], x0[W], lx[W]); cached."""
+        key = ("bilinear", h, w, H, W)
+        m = self._maps.get(key)
+        if m is None:
+            (y0, ly), (x0, lx) = bilinear_index(h, H), bilinear_index(w, W)
+            m = tuple(t.to(self.device) for t in (y0, ly, x0, lx))
+            self._maps[key] = m
+        return m
 
     def nearest_maps(self, h: int, w: int, H: int, W: int):
         """int32 device index maps of F.interpolate(mode="nearest"): (ymap[H], xmap[W]); cached per geometry."""

@@ -139,6 +139,16 @@ int gwbp_scatter_upsampled(const gwbp_caps *caps, void *workspace, size_t worksp
                            int32_t D, const int32_t *ymap, const int32_t *xmap, float scale_f, float scale_d, float *F,
                            float *d, void *stream);
 
+/* gwbp_scatter over a LOW-RESOLUTION feature map that the reference would first upsample with
+ * F.interpolate(mode="bilinear") (lseg variant, backproject.py:110-112; align_corners=False): pixel (y, x) reads
+ * h0*(w0*L[y0][x0] + w1*L[y0][x1]) + h1*(w0*L[y1][x0] + w1*L[y1][x1]) with y0 = y0map[y], y1 = min(y0+1, lr_h-1),
+ * h1 = ly[y], h0 = 1-h1 (same for x): ATen's UpSampleBilinear2d, computed while the tile's slab is staged.  The maps
+ * are device arrays of view.height / view.width entries (engine.bilinear_index builds them like ATen does). */
+int gwbp_scatter_bilinear(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                          const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c, int32_t D, int32_t lr_h,
+                          int32_t lr_w, const int32_t *y0, const float *ly, const int32_t *x0, const float *lx,
+                          float scale_f, float scale_d, float *F, float *d, void *stream);
+
 /* Forward render (what rasterization() returns): out[p,:] = sum_g w_g(p) * colors[g,:], out is [H,W,D]. */
 int gwbp_render(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                 const float *colors, int32_t D, float *out, void *stream);

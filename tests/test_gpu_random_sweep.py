@@ -197,3 +197,29 @@ def test_wide_scatter_kernel_with_nearest_upsampled_map(orc, dev):
     eng.set_narrow_scatter(True)
     with pytest.raises(gsbp_amd.GwbpError):
         eng.accumulate_d(view, d2)  # a narrow blend leaves no weight sums
+
+
+@pytest.mark.parametrize("D", [512, 48, 130], ids=["D512_fast_kernel", "D48_small_kernel", "D130_generic_kernel"])
+def test_scatter_bilinear_upsampled_lowres_map(orc, dev, D):
+    """lseg variant (backproject.py:108-113): the normalised low-resolution map [h,w,D] is upsampled bilinearly
+    (align_corners=False) while the slabs are staged; the oracle gets F.interpolate's materialised map."""
+    seed, n, W, H, s0 = 41, 2500, 150, 90, 0.03
+    means, quats, scales, opac = _scene(seed, n, s0)
+    vm, K = _camera(seed, W, H)
+    low = torch.nn.functional.normalize(torch.randn(23, 31, D, generator=torch.Generator().manual_seed(seed)), dim=2)
+    up = torch.nn.functional.interpolate(low.permute(2, 0, 1)[None], size=(H, W), mode="bilinear",
+                                         align_corners=False)[0].permute(1, 2, 0)
+    eng = gsbp_amd.Engine(n, W, H, device=dev)
+    view = eng.view(vm, K, W, H)
+    F = torch.zeros(n, D, device=dev)
+    d = torch.zeros(n, device=dev)
+    eng.project(view, *[t.to(dev) for t in (means, quats, scales, opac)])
+    eng.bin_sort(view)
+    eng.blend_weights(view)
+    eng.scatter(view, low.to(dev), F, d, upsample="bilinear")
+    Fr = np.zeros((n, D), np.float64)
+    dr = np.zeros(n, np.float64)
+    orc.backproject_view(*[t.numpy() for t in (means, quats, scales, opac)], vm.numpy(), K.numpy(), W, H,
+                         np.ascontiguousarray(up.numpy()), Fr, dr)
+    assert rel_row_err(F.cpu().numpy(), Fr) <= 1e-4
+    assert rel_row_err(d.cpu().numpy()[:, None], dr[:, None]) <= 1e-4

@@ -99,3 +99,22 @@ def test_nearest_index_matches_torch_interpolate():
         src = torch.arange(n_in, dtype=torch.float32).reshape(1, 1, 1, n_in)
         ref = torch.nn.functional.interpolate(src, size=(1, n_out), mode="nearest")[0, 0, 0].to(torch.int32)
         assert torch.equal(gsbp_amd.nearest_index(n_in, n_out), ref), (n_in, n_out)
+
+
+def test_bilinear_index_matches_torch_interpolate():
+    """The maps gwbp_scatter_bilinear consumes, applied on the CPU, must reproduce F.interpolate(mode="bilinear",
+    align_corners=False) (backproject.py:110-112)."""
+    g = torch.Generator().manual_seed(3)
+    for (h, w), (H, W) in (((24, 24), (106, 160)), ((7, 5), (33, 64)), ((16, 9), (16, 9)), ((3, 4), (10, 2)), ((1, 6), (5, 19))):
+        low = torch.randn(h, w, 6, generator=g)
+        ref = torch.nn.functional.interpolate(low.permute(2, 0, 1)[None], size=(H, W), mode="bilinear",
+                                              align_corners=False)[0].permute(1, 2, 0)
+        (y0, ly), (x0, lx) = gsbp_amd.bilinear_index(h, H), gsbp_amd.bilinear_index(w, W)
+        y0, x0 = y0.long(), x0.long()
+        y1, x1 = (y0 + 1).clamp(max=h - 1), (x0 + 1).clamp(max=w - 1)
+        h1, w1 = ly[:, None, None], lx[None, :, None]
+        h0, w0 = 1 - h1, 1 - w1
+        a, b = low[y0][:, x0], low[y0][:, x1]
+        c, d = low[y1][:, x0], low[y1][:, x1]
+        mine = h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d)
+        assert float((mine - ref).abs().max()) <= 2e-5, ((h, w), (H, W))  # ATen vectorises the index arithmetic differently: ~5e-6
