@@ -498,3 +498,25 @@ def test_driver_grows_the_workspace_on_overflow(dev, pipeline):
     b, Fb, db, _ = gsbp_amd.create_feature_field(*args, pipeline=pipeline, return_partials=True)
     assert rel_row_err(Fa.cpu().numpy(), Fb.cpu().numpy()) <= 1e-5
     assert np.abs(da.cpu().numpy() - db.cpu().numpy()).max() <= 1e-5 * float(db.max())
+
+
+def test_create_feature_field_bilinear_matches_materialised(dev):
+    """The driver with upsample="bilinear" (low-resolution maps handed over) against the driver fed with
+    F.interpolate(mode="bilinear", align_corners=False)'s materialised maps (backproject.py:108-113)."""
+    cfg, sc = scene_np("T1")
+    d = to_dev(sc, dev)
+    D, lh, lw = 128, 12, 17
+    lows = [torch.nn.functional.normalize(torch.randn(lh, lw, D, generator=torch.Generator().manual_seed(40 + v)), dim=2).to(dev)
+            for v in range(3)]
+
+    def full(v):
+        t = torch.nn.functional.interpolate(lows[v].permute(2, 0, 1)[None], size=(cfg.height, cfg.width), mode="bilinear",
+                                            align_corners=False)
+        return t[0].permute(1, 2, 0)
+
+    args = (d["means"], d["quats"], d["scales"], d["opac"], d["vms"][:3], d["K"], cfg.width, cfg.height)
+    a = gsbp_amd.create_feature_field(*args, feature_fn=lambda v: lows[v], dim=D, upsample="bilinear")
+    b = gsbp_amd.create_feature_field(*args, feature_fn=full, dim=D)
+    c = gsbp_amd.create_feature_field(*args, feature_fn=lambda v: lows[v], dim=D, upsample="bilinear", pipeline=False)
+    assert rel_row_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
+    assert rel_row_err(c.cpu().numpy(), b.cpu().numpy()) <= 2e-5
