@@ -42,24 +42,40 @@ for case in range(n_cases):
     vm[:3, :3], vm[:3, 3] = R, -R @ c
     f = float(rng.uniform(0.5, 2.0)) * max(W, H)
     K = torch.tensor([[f, 0, W / 2 + float(rng.uniform(-3, 3))], [0, f * float(rng.uniform(0.8, 1.2)), H / 2], [0, 0, 1.0]])
-    feats = torch.randn(H, W, D, generator=g)
-    if D < 4:
-        feats = feats.abs()
+    up = rng.choice([None, None, "nearest", "bilinear"])
+    if up is not None:  # a low-resolution map; the oracle gets F.interpolate's materialised version
+        lh, lw = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        low = torch.randn(lh, lw, D, generator=g)
+        if D < 4:
+            low = low.abs()
+        kw = dict(mode="nearest") if up == "nearest" else dict(mode="bilinear", align_corners=False)
+        feats = torch.nn.functional.interpolate(low.permute(2, 0, 1)[None], size=(H, W), **kw)[0].permute(1, 2, 0).contiguous()
+    else:
+        feats = torch.randn(H, W, D, generator=g)
+        if D < 4:
+            feats = feats.abs()
     layout = rng.choice(["hwc", "chw", "pad"])
-    fd = feats.to(dev)
+    fd = (low if up is not None else feats).to(dev)
     if layout == "chw":
         fd = fd.permute(2, 0, 1).contiguous().permute(1, 2, 0)
     elif layout == "pad":
-        buf = torch.zeros(H, W + 2, D + 4, device=dev)
-        buf[:, :W, :D] = fd
-        fd = buf[:, :W, :D]
+        buf = torch.zeros(fd.shape[0], fd.shape[1] + 2, D + 4, device=dev)
+        buf[:, :fd.shape[1], :D] = fd
+        fd = buf[:, :fd.shape[1], :D]
     wide = bool(rng.integers(0, 2))
     tight = bool(rng.integers(0, 2))
     eng = gsbp_amd.Engine(n, W, H, device=dev, tight_binning=tight, isect_cap=1 << 21, pair_cap=1 << 24)
     eng.set_narrow_scatter(not wide)
     F = torch.zeros(n, D, device=dev)
     d = torch.zeros(n, device=dev)
-    eng.backproject_view(eng.view(vm, K, W, H), means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev), fd, F, d)
+    view = eng.view(vm, K, W, H)
+    if up is None:
+        eng.backproject_view(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev), fd, F, d)
+    else:
+        eng.project(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
+        eng.bin_sort(view)
+        eng.blend_weights(view)
+        eng.scatter(view, fd, F, d, upsample=str(up))
     st = eng.stats()
     Fr, dr = np.zeros((n, D), np.float64), np.zeros(n, np.float64)
     info = orc.backproject_view(means.numpy(), quats.numpy(), scales.numpy(), opac.numpy(), vm.numpy(), K.numpy(), W, H,
@@ -70,7 +86,7 @@ for case in range(n_cases):
     ok = ok and eF <= 1e-4 and ed <= 1e-4 and (tight or st["n_isect"] == info["n_isect"])
     if not ok:
         bad += 1
-        print(f"FAIL case {seed0 + case}: N={n} {W}x{H} D={D} s0={s0:.4f} {layout} wide={wide} tight={tight} "
+        print(f"FAIL case {seed0 + case}: N={n} {W}x{H} D={D} s0={s0:.4f} {layout} up={up} wide={wide} tight={tight} "
               f"pairs {st['n_pairs']}/{info['n_pairs']} eF={eF:.2e} ed={ed:.2e} overflow={st['overflow']}", flush=True)
 print(f"{n_cases} cases, {bad} failures, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
