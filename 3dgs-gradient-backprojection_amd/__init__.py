@@ -9,4 +9,4 @@ from ._lib import GwbpError, build, lib  # noqa: F401
 from .backproject import ViewPipeline, create_feature_field, finalize_reference, prune_mask, reduce_partials, reduce_partials_sharded  # noqa: F401
 from .engine import Engine, bilinear_index, nearest_index  # noqa: F401
 from . import scene_io  # noqa: F401
-from .rasterization import rasterization, spherical_harmonics  # noqa: F401
+from .rasterization import rasterization  # noqa: F401

@@ -68,22 +68,50 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+_P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+_WS = [C.POINTER(Caps), _P, _SZ]            # caps, workspace, workspace_bytes
+_WSV = _WS + [C.POINTER(View)]              # ... + view_host
+_MAP = [_P, _I64, _I64, _I64, _I32]         # feats, fs_y, fs_x, fs_c, D
+# argument types of every entry point of include/gwbp.h: a Python int passed for an int64_t / size_t / pointer is
+# converted (and range-checked) by ctypes instead of being truncated to a C int
+ARGTYPES = {
+    "gwbp_workspace_size": [C.POINTER(Caps), C.POINTER(C.c_size_t)],
+    "gwbp_project": _WSV + [_P] * 8 + [_P],
+    "gwbp_bin_sort": _WSV + [_P] * 3 + [_P],
+    "gwbp_blend_weights": _WSV + [_P, _P],
+    "gwbp_accumulate_d": _WSV + [_F, _P, _P],
+    "gwbp_scatter": _WSV + _MAP + [_F, _F, _P, _P, _P],
+    "gwbp_scatter_upsampled": _WSV + _MAP + [_P, _P, _F, _F, _P, _P, _P],
+    "gwbp_scatter_bilinear": _WSV + _MAP + [_I32, _I32, _P, _P, _P, _P, _F, _F, _P, _P, _P],
+    "gwbp_render": _WSV + [_P, _I32, _P, _P],
+    "gwbp_render_pixels": _WSV + [_P, _I32, _P, _P, _P],
+    "gwbp_sh_colors": [_I64, _I32, _I32, _P, _P, C.POINTER(C.c_float), _P, _P],
+    "gwbp_backproject_view": _WSV + [_P] * 4 + _MAP + [_F, _F, _P, _P, _P],
+    "gwbp_finalize": [_I64, _I32, _P, _P, _P, _P],
+    "gwbp_accumulate_stats": _WS + [_P, _P],
+    "gwbp_read_stats": _WS + [C.POINTER(Stats), _P],
+    "gwbp_dump_pairs": _WSV + [_I64, _P, _P, _P, C.POINTER(C.c_int64), _P],
+}
+
 _lib: Optional[C.CDLL] = None
 
 
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise GwbpError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        path = os.environ.get("GWBP_LIB", LIB_PATH)  # GWBP_LIB: developer knob for A/B / PROFILE builds of the same ABI
+        if not os.path.exists(path):
+            raise GwbpError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU or PyTorch fallback for this path)")
-        L = C.CDLL(os.environ.get("GWBP_LIB", LIB_PATH))  # GWBP_LIB: developer knob for A/B builds of the same ABI
+        L = C.CDLL(path)
         L.gwbp_version.restype = C.c_char_p
         L.gwbp_last_error_string.restype = C.c_char_p
         for name in EXPORTS[2:]:
-            if "GWBP_LIB" in os.environ and not hasattr(L, name):
+            if path != LIB_PATH and not hasattr(L, name):
                 continue  # an older A/B build; calling the missing entry point still raises
-            getattr(L, name).restype = C.c_int
+            fn = getattr(L, name)
+            fn.restype = C.c_int
+            fn.argtypes = ARGTYPES[name]
         _lib = L
     return _lib
 

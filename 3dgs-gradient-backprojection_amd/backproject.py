@@ -4,13 +4,14 @@ and of the compressed variant (backproject_compressed.py:39-186) on top of the f
 Per view the reference does: rasterise(zeros [N,D]) -> (render*feats).sum().backward() -> grad.clone();
 rasterise(zeros [N,3]) -> render.sum().backward() -> grad[:,0]; F += ..; d += .. (backproject.py:115-151).
 Here one call (`Engine.backproject_view`) projects, sorts, blends ONCE and scatter-accumulates straight into
-F[N,D] and d[N].  Views shard across ranks (`synthetic.view_shard`); partial F/d are summed with ONE
-all-reduce (RCCL over xGMI when the process group backend is "nccl"), the 1e-12 of backproject.py:63 is
-added once after the reduction, then normalisation is row-local (backproject.py:166-169).
+F[N,D] and d[N].  Views shard across ranks (`synthetic.view_shard`); the partial F/d are summed in ONE exchange
+step (a reduce-scatter of F + an all-reduce of the N-float d; RCCL over xGMI when the process group backend is
+"nccl"), the 1e-12 of backproject.py:63 is added once after the reduction, normalisation is row-local
+(backproject.py:166-169) so every rank finalises its own row block, and one all-gather of the finalised blocks
+follows if the whole field is wanted on every rank.
 """
 from __future__ import annotations
 
-import os
 import time
 from typing import Callable, Dict, Optional, Sequence
 
@@ -35,25 +36,60 @@ def reduce_partials(F: torch.Tensor, d: torch.Tensor) -> None:
         dist.all_reduce(d, op=dist.ReduceOp.SUM)
 
 
-def reduce_partials_sharded(F: torch.Tensor, d: torch.Tensor):
-    """The exchange step as a reduce-scatter: rank r receives rows [row0, row0 + n_r) of the summed F (and d), which is
-    all the row-local finalise needs (backproject.py:166-169) -- half the xGMI traffic of the all-reduce; an all-gather
-    is only needed if one rank must hold the whole field.  Returns (F_rows, d_rows, row0).
-    Falls back to all-reduce + slice when N does not divide evenly or the backend has no reduce-scatter (gloo)."""
+def rows_per_rank(n: int, world: int) -> int:
+    """Rows of F every rank owns after the reduce-scatter: ceil(n / world); the last rank's block may be short."""
+    return -(-n // world)
+
+
+def alloc_accumulators(n: int, dim: int, device, world: Optional[int] = None):
+    """F[n, dim], d[n] zero accumulators whose STORAGE is padded to a multiple of the world size, so that the
+    reduce-scatter of reduce_partials_sharded runs in place on it (no 2 GB pad copy).  Returns (F, d, F_storage)."""
+    if world is None:
+        world = _dist()[2]
+    n_pad = rows_per_rank(n, world) * world
+    F_store = torch.zeros(n_pad, dim, device=device, dtype=torch.float32)
+    return F_store[:n], torch.zeros(n, device=device, dtype=torch.float32), F_store
+
+
+def reduce_partials_sharded(F: torch.Tensor, d: torch.Tensor, F_storage: Optional[torch.Tensor] = None):
+    """The path's single exchange step as a reduce-scatter: rank r receives rows [row0, row0 + n_r) of the summed F (and
+    the whole summed d, 4 B per Gaussian), which is all the row-local finalise needs (backproject.py:166-169) -- half
+    the xGMI traffic of an all-reduce; an all-gather of the finalised rows follows only if one rank must hold the whole
+    field.  Returns (F_rows, d_rows, row0).
+
+    N need not divide by the world size: the reduce-scatter runs on ceil(N / world) * world rows -- on `F_storage` when
+    the caller allocated F with alloc_accumulators (no copy), else on a zero-padded copy."""
     dist, rank, world = _dist()
     n = F.shape[0]
     if dist is None:  # no process group: nothing to exchange
         return F, d, 0
     # (a one-rank process group still goes through the collectives: `bench.py --force-dist` exercises the RCCL calls)
-    per = -(-n // world)
+    per = rows_per_rank(n, world)
     row0, row1 = min(rank * per, n), min((rank + 1) * per, n)
-    dist.all_reduce(d, op=dist.ReduceOp.SUM)  # 4 B per Gaussian
-    if n % world == 0 and dist.get_backend() != "gloo":
-        out = torch.empty(per, F.shape[1], device=F.device, dtype=F.dtype)
-        dist.reduce_scatter_tensor(out, F, op=dist.ReduceOp.SUM)
-        return out, d[row0:row1], row0
-    dist.all_reduce(F, op=dist.ReduceOp.SUM)
-    return F[row0:row1], d[row0:row1], row0
+    dist.all_reduce(d, op=dist.ReduceOp.SUM)
+    src = F
+    if per * world != n:
+        if F_storage is not None and F_storage.shape[0] == per * world and F_storage.data_ptr() == F.data_ptr():
+            src = F_storage
+        else:
+            src = torch.cat([F, F.new_zeros(per * world - n, F.shape[1])])
+    out = torch.empty(per, F.shape[1], device=F.device, dtype=F.dtype)
+    dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM)
+    return out[:row1 - row0], d[row0:row1], row0
+
+
+def gather_rows(rows: torch.Tensor, n: int) -> torch.Tensor:
+    """All ranks' finalised row blocks -> the whole [n, D] field on every rank (one all-gather; the reference writes one
+    features file, backproject.py:330)."""
+    dist, _, world = _dist()
+    if dist is None:
+        return rows
+    per = rows_per_rank(n, world)
+    if rows.shape[0] != per:  # the last rank's short block: pad to the common block size
+        rows = torch.cat([rows, rows.new_zeros(per - rows.shape[0], rows.shape[1])])
+    full = torch.empty(per * world, rows.shape[1], device=rows.device, dtype=rows.dtype)
+    dist.all_gather_into_tensor(full, rows.contiguous())
+    return full[:n]
 
 
 def finalize_reference(F: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
@@ -76,22 +112,24 @@ class ViewPipeline:
     (workspace reuse).  Nothing synchronises the host.
     """
 
-    def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None):
+    def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None,
+                 allow_wide: bool = True, scatter_workgroups: Optional[int] = None, side_priority: int = -1):
         self.dev = torch.device(device)
         self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev, tight_binning=True)
                                                   for _ in range(2)]
         # Scatter grid under overlap: one persistent workgroup per CU is the measured optimum once the front stage is
-        # light (C2: 4.24 ms/view at 256 vs 4.40 at 240); GWBP_PIPE_WGS overrides for tuning on other workloads.
-        if "GWBP_PIPE_WGS" in os.environ:
+        # light (C2: 4.24 ms/view at 256 vs 4.40 at 240); `scatter_workgroups` overrides.
+        if scatter_workgroups is not None:  # tuning on other workloads
             for e in self.eng:
-                e.scatter_workgroups = int(os.environ["GWBP_PIPE_WGS"])
+                e.scatter_workgroups = int(scatter_workgroups)
                 e.caps.scatter_workgroups = e.scatter_workgroups
         # High priority = a hardware queue of its own.  With default priority the side stream can land on the main
         # stream's hardware queue (it does once RCCL has created its streams: GPU_MAX_HW_QUEUES is 4), the two streams
         # then run strictly one after the other and the step is front + scatter (5.06 instead of 4.27 ms/view at C2).
         self.scatter_dim = scatter_dim
+        self.allow_wide = bool(allow_wide)
         self.choose_scatter_kernel(None, None)
-        self.side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("GWBP_SIDE_PRIO", "-1")))
+        self.side = torch.cuda.Stream(device=self.dev, priority=int(side_priority))
         self.ev_front = [torch.cuda.Event() for _ in range(2)]
         self.ev_done = [torch.cuda.Event() for _ in range(2)]
         self.accum = torch.zeros(32, dtype=torch.uint8, device=self.dev)
@@ -107,8 +145,11 @@ class ViewPipeline:
         channel) and leaves issue slots that the front stage can use at raised wave priority (4.08 vs 4.30 ms/view at
         C2), but costs more per (Gaussian, tile) record: with short records (C4: 25 pairs per record) it loses 5 %, and
         beside the 128-channel kernel the raised priority costs 6 %.  Called once without statistics (wide if the channel
-        count allows) and again by the drivers with the first views' counters."""
-        wide = (self.scatter_dim is not None and self.scatter_dim % 256 == 0 and "GWBP_NO_WIDE" not in os.environ)
+        count allows) and again by the drivers with the first views' counters.  Safe in either direction while fronts
+        are pending: every Engine remembers whether the view in its workspace was blended with the half-tile lists, and
+        scatters a view blended without them through the 128-channel kernel (front() likewise recorded whether it has
+        already added that view's denominators)."""
+        wide = self.allow_wide and self.scatter_dim is not None and self.scatter_dim % 256 == 0
         if wide and n_pairs is not None and n_headers:
             wide = n_pairs / n_headers >= self.WIDE_MIN_PAIRS_PER_RECORD
         self.wide = wide
@@ -164,7 +205,8 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                          feature_fn: Callable[[int], torch.Tensor], dim: int, reduction: str = "sum",
                          encoder: Optional[torch.Tensor] = None, engine: Optional[Engine] = None,
                          views: Optional[Sequence[int]] = None, view_fn=None, pipeline: bool = True,
-                         return_partials: bool = False, verbose: bool = False, upsample: Optional[str] = None):
+                         return_partials: bool = False, verbose: bool = False, upsample: Optional[str] = None,
+                         gather: bool = True, allow_wide: bool = True):
     """Build the [N, dim_out] per-Gaussian feature field.
 
     means/quats/scales/opacities: post-activation Gaussians (backproject.py:55-57), device tensors.
@@ -179,13 +221,16 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     views: explicit list of view indices for this rank (default: interleaved shard over the process group).
     view_fn: injection point for the per-view accumulate (tests drive the sharding/reduction logic on CPU).
     pipeline: overlap the front stages of view v+1 with the scatter of view v (ViewPipeline).
+    gather: under a process group, all-gather the finalised row blocks so that every rank returns the whole [N, dim_out]
+    field; False returns this rank's block only (rows row0 .. of `return_partials`' stats["row0"]).
+    return_partials: also return (F_rows, d, stats): the summed, un-normalised accumulators (this rank's row block of F,
+    all of d) and the counters.
     """
     dist, rank, world = _dist()
     n = means.shape[0]
     d_out = dim if encoder is None else encoder.shape[1]
     dev = means.device
-    F = torch.zeros(n, d_out, device=dev, dtype=torch.float32)
-    d = torch.zeros(n, device=dev, dtype=torch.float32)
+    F, d, F_store = alloc_accumulators(n, d_out, dev, world)
     my_views = list(views) if views is not None else view_shard(viewmats.shape[0], rank, world)
     vm_host, K_host = viewmats.detach().cpu(), K.detach().cpu()  # one D2H copy, not one per view
     if reduction == "sum":
@@ -203,6 +248,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
             if pipeline and len(my_views) > 1:
                 # (bilinear maps are staged by the 128-channel kernel only: no wide kernel, no front priority)
                 pipe = ViewPipeline(n, width, height, dev, scatter_dim=None if upsample == "bilinear" else d_out,
+                                    allow_wide=allow_wide,
                                     engines=[eng, Engine(n, width, height, device=dev,
                                                                                 tight_binning=eng.tight_binning,
                                                                                 isect_cap=eng.isect_cap,
@@ -236,6 +282,9 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                         eng.scatter(view, feats, F, d, sf, sd, upsample=upsample)
                     eng.accumulate_stats(accum)
                 stats = Engine.decode_stats(accum)  # synchronises
+            if stats["overflow"] & 4:
+                raise RuntimeError("a view was scattered with a kernel that did not match its blend (gwbp_stats.overflow "
+                                   "bit 2): F and d are incomplete")
             if not stats["overflow"]:
                 break
             if attempt == 5:
@@ -250,12 +299,17 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
             if encoder is not None:
                 feats = feats @ encoder
             view_fn(v, feats)
-    reduce_partials(F, d)
-    out = eng.finalize(F, d) if eng is not None else finalize_reference(F, d)
+    # The single exchange step: reduce-scatter of F (+ all-reduce of d), row-local finalise of this rank's block
+    # (backproject.py:166-169 needs nothing but the row), and an all-gather of the finalised blocks only when the caller
+    # wants the whole field on every rank (the reference writes one file, backproject.py:330).
+    F_rows, d_rows, row0 = reduce_partials_sharded(F, d, F_store)
+    out_rows = eng.finalize(F_rows, d_rows) if eng is not None else finalize_reference(F_rows, d_rows)
+    out = gather_rows(out_rows, n) if gather else out_rows
     if verbose and rank == 0:
         print("Time taken for feature backprojection", time.time() - t0)  # backproject.py:171
     if return_partials:
-        return out, F, d, stats
+        # F_rows/d: the SUMMED accumulators (this rank's row block of F starting at row0, and all of d)
+        return out, F_rows, d, dict(stats, row0=row0)
     return out
 
 

@@ -294,8 +294,9 @@ __global__ __launch_bounds__(256) void k_dump_pairs(ViewDev V, const u32 *__rest
     }
 }
 
-__global__ void k_pool_stats(const u32 *__restrict__ shards, Counters *__restrict__ ctr)
+__global__ void k_pool_stats(const u32 *__restrict__ shards, Counters *__restrict__ ctr, u32 blend_kind)
 {
+    ctr->blend_kind = blend_kind; // which scatter kernels may read this view's store (half-tile lists, weight sums)
     u32 mx = 0;
     for (int i = 0; i < kShards; ++i)
         mx = max(mx, shards[i * 16]);
@@ -308,10 +309,8 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
     const int n_tiles = V.tile_w * V.tile_h;
     const int fin = sort_passes(n_tiles) & 1;
     // profiling knobs, read once per process (results are invalid when GWBP_ABLATE_BLEND is set)
-    static const int ablate = getenv("GWBP_ABLATE_BLEND") ? atoi(getenv("GWBP_ABLATE_BLEND")) : 0;
-    static int extra_lds = -1; // experiment knob: pad the workgroup's LDS footprint to cap co-residency
-    if (extra_lds < 0)
-        extra_lds = getenv("GWBP_BLEND_LDS") ? atoi(getenv("GWBP_BLEND_LDS")) : 0;
+    const int ablate = profile_knob("GWBP_ABLATE_BLEND");
+    const int extra_lds = profile_knob("GWBP_BLEND_LDS"); // experiment knob: pad the workgroup's LDS footprint
 #define GWBP_BLEND(H)                                                                                                 \
     hipLaunchKernelGGL(k_blend<H>, dim3(n_tiles), dim3(64), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d,  \
                        W.counters, W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, W.tile_order, alphas,  \
@@ -321,7 +320,8 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
     else
         GWBP_BLEND(true);
 #undef GWBP_BLEND
-    hipLaunchKernelGGL(k_pool_stats, dim3(1), dim3(1), 0, s, W.shards, W.counters);
+    hipLaunchKernelGGL(k_pool_stats, dim3(1), dim3(1), 0, s, W.shards, W.counters,
+                       (L.flags & GWBP_FLAG_NARROW_SCATTER) ? 0u : kBlendHalves);
     return check_hip(hipGetLastError(), "blend launch");
 }
 

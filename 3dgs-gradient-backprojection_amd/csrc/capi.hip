@@ -1,6 +1,7 @@
 // capi.hip -- extern "C" entry points of libgwbp.so (see include/gwbp.h for the contract).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "gwbp_dev.h"
@@ -24,6 +25,62 @@ int check_hip(hipError_t e, const char *what)
         return GWBP_OK;
     set_error((int)e, "%s: %s", what, hipGetErrorString(e));
     return (int)e;
+}
+
+namespace {
+struct DevCache {
+    int n_cu;
+    unsigned lds_mask;
+};
+DevCache g_dev[64]; // benign races: every writer stores the same value
+DevCache *dev_cache()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return nullptr;
+    return &g_dev[dev];
+}
+} // namespace
+
+int device_cus(int *n_cu)
+{
+    DevCache *c = dev_cache();
+    if (!c)
+        return set_error(GWBP_EINVAL, "cannot query the current device");
+    if (c->n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return set_error(GWBP_EINVAL, "cannot query the device for the persistent scatter grid");
+        c->n_cu = v > 0 ? v : 256;
+    }
+    *n_cu = c->n_cu;
+    return GWBP_OK;
+}
+
+int ensure_dynamic_lds(const void *func, int bytes, int slot)
+{
+    DevCache *c = dev_cache();
+    if (!c)
+        return set_error(GWBP_EINVAL, "cannot query the current device");
+    if (c->lds_mask & (1u << slot))
+        return GWBP_OK;
+    const int rc = check_hip(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes),
+                             "dynamic LDS attribute");
+    if (rc == GWBP_OK)
+        c->lds_mask |= 1u << slot;
+    return rc;
+}
+
+int profile_knob(const char *name)
+{
+#ifdef GWBP_PROFILE
+    const char *v = getenv(name);
+    return v ? atoi(v) : 0;
+#else
+    (void)name;
+    return 0;
+#endif
 }
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -163,7 +220,14 @@ using namespace gwbp;
 
 extern "C" {
 
-const char *gwbp_version(void) { return "libgwbp gfx950 r1"; }
+const char *gwbp_version(void)
+{
+#ifdef GWBP_PROFILE
+    return "libgwbp gfx950 r2 (PROFILE build: ablation knobs live, results may be invalid)";
+#else
+    return "libgwbp gfx950 r2";
+#endif
+}
 const char *gwbp_last_error_string(void) { return g_err; }
 
 int gwbp_workspace_size(const gwbp_caps *caps, size_t *bytes_host)

@@ -76,8 +76,10 @@ struct Counters {
     u32 n_headers;
     u32 pool_head;
     u32 overflow;
-    u32 reserved;
+    u32 blend_kind; // gwbp_stats::reserved: kBlendHalves once k_blend<true> has written the half-tile lists of THIS view
 };
+constexpr u32 kBlendHalves = 1u;
+constexpr u32 kOverflowMismatch = 4u; // gwbp_stats::overflow bit 2, see include/gwbp.h
 static_assert(sizeof(Counters) == sizeof(gwbp_stats), "Counters must mirror gwbp_stats");
 
 struct Layout {
@@ -114,6 +116,13 @@ int make_layout(const gwbp_caps *caps, Layout *L);
 int bind_workspace(const gwbp_caps *caps, void *ws, size_t bytes, Layout *L, Ws *W);
 int set_error(int code, const char *fmt, ...);
 int check_hip(hipError_t e, const char *what);
+// Per-device facts, cached per device ORDINAL (a process may drive several GPUs): CU count of the current device, and
+// "this kernel's dynamic-LDS limit has been raised on the current device" (slot = one bit per kernel, < 32).
+int device_cus(int *n_cu);
+int ensure_dynamic_lds(const void *func, int bytes, int slot);
+// Profiling / ablation knobs (GWBP_ABLATE, GWBP_ABLATE_BLEND, GWBP_BLEND_LDS): an environment variable is read only by a
+// library built with -DGWBP_PROFILE (make PROFILE=1 -> libgwbp_profile.so); the product library always gets 0.
+int profile_knob(const char *name);
 
 struct ViewDev { // per-launch copy of gwbp_view (kernel argument, 128 B)
     float R[9];

@@ -245,8 +245,13 @@ static int chunk_pitch(int D)
 // denominator operation.
 __global__ __launch_bounds__(256) void k_accum_d(const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
                                                  const Header *__restrict__ headers, float scale_d,
-                                                 float *__restrict__ dsum_out)
+                                                 float *__restrict__ dsum_out, Counters *__restrict__ ctr)
 {
+    if (ctr->blend_kind != kBlendHalves) { // no weight sums in this view's headers: refuse, flag (see k_scatter_wide)
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            atomicOr(&ctr->overflow, kOverflowMismatch);
+        return;
+    }
     const int tile = blockIdx.x;
     const u32 nh = hdr_count[tile];
     const Header *hb = headers + tile_offsets[tile];
@@ -260,7 +265,8 @@ int launch_accum_d(const Layout &L, const Ws &W, const ViewDev &V, float scale_d
         return set_error(GWBP_EINVAL, "gwbp_accumulate_d needs a blend without GWBP_FLAG_NARROW_SCATTER (no weight sums)");
     const int n_tiles = V.tile_w * V.tile_h;
     if (d && n_tiles > 0)
-        hipLaunchKernelGGL(k_accum_d, dim3(n_tiles), dim3(256), 0, s, W.tile_offsets, W.hdr_count, W.headers, scale_d, d);
+        hipLaunchKernelGGL(k_accum_d, dim3(n_tiles), dim3(256), 0, s, W.tile_offsets, W.hdr_count, W.headers, scale_d, d,
+                           W.counters);
     return check_hip(hipGetLastError(), "accum_d launch");
 }
 
@@ -272,18 +278,13 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap
     const int n_chunks = (D + kChunk - 1) / kChunk;
     const int pitch = chunk_pitch(D);
     const size_t lds_bytes = (size_t)kTilePix * pitch * sizeof(float) + 16;
-    static bool attr_done = false; // benign race: idempotent
-    if (!attr_done) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64),
-                           "scatter LDS attribute");
+    {
+        const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(k_scatter), 160 * 1024 - 64, 5);
         if (rc)
             return rc;
-        attr_done = true;
     }
     // fast paths: D % 256 == 0 channel-contiguous (scatter_wide.hip); D % 128 == 0 or D <= 64, any strides (scatter_full.hip)
-    static const bool no_wide = getenv("GWBP_NO_WIDE") != nullptr; // A/B knob
-    if (D % 256 == 0 && M.fs_c == 1 && !M.bilinear() && !no_wide && !(L.flags & GWBP_FLAG_NARROW_SCATTER)) {
+    if (D % 256 == 0 && M.fs_c == 1 && !M.bilinear() && !(L.flags & GWBP_FLAG_NARROW_SCATTER)) {
         if (d) {
             const int rc = launch_accum_d(L, W, V, scale_d, d, s);
             if (rc)

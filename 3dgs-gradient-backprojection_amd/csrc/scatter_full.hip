@@ -472,36 +472,27 @@ int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const Fe
     const int n_chunks = small ? 1 : D / kChunk;
     const int pitch = small ? ((D + 3) & ~3) : kChunk;
     const size_t lds_bytes = (size_t)kTilePix * pitch * sizeof(float) + 16; // slab + work counter + two item slots
-    static bool attr_done = false; // benign race: idempotent
-    if (!attr_done) {
-        const void *fns[4] = {reinterpret_cast<const void *>(k_scatter_full<false, 0>),
-                              reinterpret_cast<const void *>(k_scatter_full<false, 1>),
-                              reinterpret_cast<const void *>(k_scatter_full<false, 2>),
-                              reinterpret_cast<const void *>(k_scatter_full<true, 0>)};
-        for (int i = 0; i < 4; ++i) {
-            const int rc = check_hip(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                         i < 3 ? (int)kLdsBytes : 65536 + 16),
-                                     "scatter_full LDS attribute");
-            if (rc)
-                return rc;
-        }
-        attr_done = true;
+    const void *fns[4] = {reinterpret_cast<const void *>(k_scatter_full<false, 0>),
+                          reinterpret_cast<const void *>(k_scatter_full<false, 1>),
+                          reinterpret_cast<const void *>(k_scatter_full<false, 2>),
+                          reinterpret_cast<const void *>(k_scatter_full<true, 0>)};
+    for (int i = 0; i < 4; ++i) {
+        const int rc = ensure_dynamic_lds(fns[i], i < 3 ? (int)kLdsBytes : 65536 + 16, 1 + i);
+        if (rc)
+            return rc;
     }
-    static const char *ab = getenv("GWBP_ABLATE"); // profiling ablation only, read once (results are invalid when set)
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return set_error(GWBP_EINVAL, "cannot query the device for the persistent scatter grid");
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int n_cu = 0;
+    {
+        const int rc = device_cus(&n_cu);
+        if (rc)
+            return rc;
     }
     // persistent workgroups: one per CU (two for the small-D path whose slab is <= 64 KB); caps.scatter_workgroups
     // overrides; always a multiple of the 8 XCD classes
     int grid = L.scatter_wgs > 0 ? L.scatter_wgs : (small ? 2 * n_cu : n_cu);
     grid = (grid + 7) & ~7;
     u32 *queues = W.shards + kShards * 16;
-    const int dbg = ab ? atoi(ab) : 0;
+    const int dbg = profile_knob("GWBP_ABLATE");
 #define GWBP_LAUNCH(S, Vc)                                                                                            \
     hipLaunchKernelGGL((k_scatter_full<S, Vc>), dim3(grid), dim3(kThreads), lds_bytes, s, V, n_chunks, W.tile_offsets,  \
                        W.hdr_count, W.headers, W.wpool, M, pitch, D, scale_f, scale_d, F, d, queues, dbg)

@@ -88,8 +88,15 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     ViewDev V, int n_chunks, const u32 *__restrict__ tile_offsets, const u32 *__restrict__ cnt_a,
     const u32 *__restrict__ cnt_b, const HalfHdr *__restrict__ half_a, const HalfHdr *__restrict__ half_b,
     const WPair *__restrict__ wpool, FeatMap M, int D, float scale_f, float *__restrict__ F,
-    u32 *__restrict__ queues, float *__restrict__ carry_all, int dbg)
+    u32 *__restrict__ queues, float *__restrict__ carry_all, Counters *__restrict__ ctr, int dbg)
 {
+    // The half-tile lists exist only if THIS view was blended without GWBP_FLAG_NARROW_SCATTER; otherwise they are
+    // uninitialised or a previous view's.  Refuse (F untouched, overflow bit 2 raised) instead of scattering garbage.
+    if (uniform(ctr->blend_kind) != kBlendHalves) {
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            atomicOr(&ctr->overflow, kOverflowMismatch);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     u32 *s_next = reinterpret_cast<u32 *>(lds + kSlabFloats);
     u32 *s_item = s_next + 1; // two slots: iteration k reads [k & 1], thread 0 fills [(k + 1) & 1] meanwhile
@@ -314,24 +321,12 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
 int launch_scatter_wide(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
                         float *F, hipStream_t s)
 {
-    static bool attr_done = false; // benign race: idempotent
-    if (!attr_done) {
-        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes),
-                                 "scatter_wide LDS attribute");
-        if (rc)
-            return rc;
-        attr_done = true;
-    }
-    static const char *ab = getenv("GWBP_ABLATE"); // profiling ablation only, read once (results are invalid when set)
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return set_error(GWBP_EINVAL, "cannot query the device for the persistent scatter grid");
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(k_scatter_wide), (int)kLdsBytes, 0);
+    if (rc)
+        return rc;
+    int n_cu = 0;
+    if ((rc = device_cus(&n_cu)))
+        return rc;
     // persistent workgroups: one per CU, at most kCarryWgs (each owns a carry slice), a multiple of the 8 XCD classes
     int grid = L.scatter_wgs > 0 ? L.scatter_wgs : n_cu;
     grid = (grid + 7) & ~7;
@@ -340,7 +335,7 @@ int launch_scatter_wide(const Layout &L, const Ws &W, const ViewDev &V, const Fe
     u32 *queues = W.shards + kShards * 16;
     hipLaunchKernelGGL(k_scatter_wide, dim3(grid), dim3(kThreads), kLdsBytes, s, V, D / kWide, W.tile_offsets,
                        W.half_count[0], W.half_count[1], W.half[0], W.half[1], W.wpool, M, D, scale_f, F, queues, W.carry,
-                       ab ? atoi(ab) : 0);
+                       W.counters, profile_knob("GWBP_ABLATE"));
     return check_hip(hipGetLastError(), "scatter_wide launch");
 }
 

@@ -71,6 +71,7 @@ class Engine:
         # tight_binning: GWBP_FLAG_TIGHT_BINNING -- same F, d, weights and renders, shorter tile lists; off by default
         # because meta["isect_ids"] of the drop-in operator must show gsplat's 3-sigma binning
         self.tight_binning = bool(tight_binning)
+        self._halves = False  # the workspace holds the half-tile lists + weight sums of the view blended last
         self._alloc()
 
     def set_front_priority(self, on: bool) -> None:
@@ -95,7 +96,7 @@ class Engine:
         self.caps = Caps(self.n, self.isect_cap, self.pair_cap, self.max_w, self.max_h, self.scatter_workgroups,
                          (_lib.FLAG_TIGHT_BINNING if self.tight_binning else 0) | _lib.FLAG_NARROW_SCATTER)
         nbytes = C.c_size_t(0)
-        check(self.lib.gwbp_workspace_size(C.byref(self.caps), C.byref(nbytes)), "gwbp_workspace_size")
+        self._call("gwbp_workspace_size", C.byref(self.caps), C.byref(nbytes))
         self.ws_bytes = int(nbytes.value)
         self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.device)
         off = (-self.ws.data_ptr()) % 256
@@ -116,6 +117,12 @@ class Engine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _call(self, name: str, *args):
+        """One C-ABI call with this engine's device current: libgwbp launches on the CURRENT HIP device, while the
+        workspace, the tensors and the stream handle belong to self.device (a process may hold engines on several)."""
+        with torch.cuda.device(self.device):
+            check(getattr(self.lib, name)(*args), name)
+
     def _args(self):
         return C.byref(self.caps), self._ws_ptr, C.c_size_t(self.ws_bytes)
 
@@ -134,9 +141,9 @@ class Engine:
                        means2d=torch.empty(self.n, 2, device=self.device),
                        depths=torch.empty(self.n, device=self.device),
                        conics=torch.empty(self.n, 3, device=self.device))
-        check(self.lib.gwbp_project(*self._args(), C.byref(view), ptr(means), ptr(quats), ptr(scales),
+        self._call("gwbp_project", *self._args(), C.byref(view), ptr(means), ptr(quats), ptr(scales),
                                     ptr(opacities), ptr(out.get("radii")), ptr(out.get("means2d")),
-                                    ptr(out.get("depths")), ptr(out.get("conics")), self._stream()), "gwbp_project")
+                                    ptr(out.get("depths")), ptr(out.get("conics")), self._stream())
         return out
 
     def bin_sort(self, view, want_outputs=False):
@@ -146,15 +153,17 @@ class Engine:
             out = dict(isect_ids=torch.empty(self.isect_cap, dtype=torch.int64, device=self.device),
                        flatten_ids=torch.empty(self.isect_cap, dtype=torch.int32, device=self.device),
                        tile_offsets=torch.empty(nt + 1, dtype=torch.int32, device=self.device))
-        check(self.lib.gwbp_bin_sort(*self._args(), C.byref(view), ptr(out.get("isect_ids")),
-                                     ptr(out.get("flatten_ids")), ptr(out.get("tile_offsets")), self._stream()),
-              "gwbp_bin_sort")
+        self._call("gwbp_bin_sort", *self._args(), C.byref(view), ptr(out.get("isect_ids")),
+                                     ptr(out.get("flatten_ids")), ptr(out.get("tile_offsets")), self._stream())
         return out
+
+    def _wide_requested(self) -> bool:
+        return not (self.caps.flags & _lib.FLAG_NARROW_SCATTER)
 
     def blend_weights(self, view, want_alphas=False):
         alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
-        check(self.lib.gwbp_blend_weights(*self._args(), C.byref(view), ptr(alphas), self._stream()),
-              "gwbp_blend_weights")
+        self._halves = self._wide_requested()  # k_blend<HALVES> writes the lists only without NARROW_SCATTER
+        self._call("gwbp_blend_weights", *self._args(), C.byref(view), ptr(alphas), self._stream())
         return alphas
 
     @staticmethod
@@ -172,8 +181,10 @@ class Engine:
         """d += scale_d * sum_p w from the blend's per-record weight sums (needs a blend with the wide scatter enabled)."""
         if d is None or d.dtype != torch.float32 or not d.is_cuda or d.shape != (self.n,) or not d.is_contiguous():
             raise GwbpError("d must be a contiguous float32 HIP tensor [N]")
-        check(self.lib.gwbp_accumulate_d(*self._args(), C.byref(view), C.c_float(scale_d), ptr(d), self._stream()),
-              "gwbp_accumulate_d")
+        if not self._halves:
+            raise GwbpError("accumulate_d needs a view blended with the 256-channel scatter kernel enabled "
+                            "(set_narrow_scatter(False) BEFORE blend_weights): this view's headers hold no weight sums")
+        self._call("gwbp_accumulate_d", *self._args(), C.byref(view), C.c_float(scale_d), ptr(d), self._stream())
 
     def scatter(self, view, feats, F, d, scale_f=1.0, scale_d=1.0, upsample: Optional[str] = None):
         """F += scale_f * sum_p w feats[p], d += scale_d * sum_p w from the view's weight store.
@@ -181,12 +192,21 @@ class Engine:
         upsample="nearest" / "bilinear": feats is a LOW-RESOLUTION map [h,w,D]; the result equals scattering
         F.interpolate(feats, size=(H,W), mode=...) (dino: backproject.py:244-248; lseg: backproject.py:110-112,
         align_corners=False) without building that map -- the interpolation happens while the tile slabs are staged."""
+        if self._wide_requested() and not self._halves:
+            # This view was blended with GWBP_FLAG_NARROW_SCATTER (no half-tile lists, no weight sums) and the flag has
+            # been cleared since: the 256-channel kernel would read another view's lists.  Scatter it with the
+            # 128-channel kernel, which needs only the headers every blend writes.
+            self.caps.flags |= _lib.FLAG_NARROW_SCATTER
+            try:
+                return self.scatter(view, feats, F, d, scale_f, scale_d, upsample)
+            finally:
+                self.caps.flags &= ~_lib.FLAG_NARROW_SCATTER
         if upsample is None:
             sy, sx, sc, D = self._feat_strides(feats, view)
             self._check_acc(F, d, D)
-            check(self.lib.gwbp_scatter(*self._args(), C.byref(view), ptr(feats), C.c_int64(sy), C.c_int64(sx),
+            self._call("gwbp_scatter", *self._args(), C.byref(view), ptr(feats), C.c_int64(sy), C.c_int64(sx),
                                         C.c_int64(sc), D, C.c_float(scale_f), C.c_float(scale_d), ptr(F), ptr(d),
-                                        self._stream()), "gwbp_scatter")
+                                        self._stream())
             return
         if upsample not in ("nearest", "bilinear"):
             raise GwbpError(f"upsample must be None, 'nearest' or 'bilinear', got {upsample!r}")
@@ -194,17 +214,16 @@ class Engine:
         self._check_acc(F, d, D)
         if upsample == "bilinear":
             y0, ly, x0, lx = self.bilinear_maps(feats.shape[0], feats.shape[1], view.height, view.width)
-            check(self.lib.gwbp_scatter_bilinear(*self._args(), C.byref(view), ptr(feats), C.c_int64(sy),
+            self._call("gwbp_scatter_bilinear", *self._args(), C.byref(view), ptr(feats), C.c_int64(sy),
                                                  C.c_int64(sx), C.c_int64(sc), D, int(feats.shape[0]),
                                                  int(feats.shape[1]), ptr(y0), ptr(ly), ptr(x0), ptr(lx),
                                                  C.c_float(scale_f), C.c_float(scale_d), ptr(F), ptr(d),
-                                                 self._stream()), "gwbp_scatter_bilinear")
+                                                 self._stream())
             return
         ymap, xmap = self.nearest_maps(feats.shape[0], feats.shape[1], view.height, view.width)
-        check(self.lib.gwbp_scatter_upsampled(*self._args(), C.byref(view), ptr(feats), C.c_int64(sy), C.c_int64(sx),
+        self._call("gwbp_scatter_upsampled", *self._args(), C.byref(view), ptr(feats), C.c_int64(sy), C.c_int64(sx),
                                               C.c_int64(sc), D, ptr(ymap), ptr(xmap), C.c_float(scale_f),
-                                              C.c_float(scale_d), ptr(F), ptr(d), self._stream()),
-              "gwbp_scatter_upsampled")
+                                              C.c_float(scale_d), ptr(F), ptr(d), self._stream())
 
     def bilinear_maps(self, h: int, w: int, H: int, W: int):
         """device maps of F.interpolate(mode="bilinear", align_corners=False): (y0[H], ly[H], x0[W], lx[W]); cached."""
@@ -229,8 +248,7 @@ class Engine:
         colors = _req(colors, "colors")
         D = colors.shape[1]
         out = torch.empty(view.height, view.width, D, device=self.device)
-        check(self.lib.gwbp_render(*self._args(), C.byref(view), ptr(colors), D, ptr(out), self._stream()),
-              "gwbp_render")
+        self._call("gwbp_render", *self._args(), C.byref(view), ptr(colors), D, ptr(out), self._stream())
         return out
 
     def render_pixels(self, view, colors, want_alphas=True):
@@ -239,8 +257,8 @@ class Engine:
         D = colors.shape[1]
         out = torch.empty(view.height, view.width, D, device=self.device)
         alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
-        check(self.lib.gwbp_render_pixels(*self._args(), C.byref(view), ptr(colors), D, ptr(out), ptr(alphas),
-                                          self._stream()), "gwbp_render_pixels")
+        self._call("gwbp_render_pixels", *self._args(), C.byref(view), ptr(colors), D, ptr(out), ptr(alphas),
+                                          self._stream())
         return out, alphas
 
     def sh_colors(self, degree: int, means, coeffs, campos):
@@ -251,14 +269,15 @@ class Engine:
             raise GwbpError(f"SH coefficients must be [N,K,3], got {tuple(coeffs.shape)}")
         out = torch.empty(means.shape[0], 3, device=self.device)
         cp = (C.c_float * 3)(*[float(v) for v in campos])
-        check(self.lib.gwbp_sh_colors(C.c_int64(means.shape[0]), int(degree), coeffs.shape[1], ptr(means), ptr(coeffs),
-                                      cp, ptr(out), self._stream()), "gwbp_sh_colors")
+        self._call("gwbp_sh_colors", C.c_int64(means.shape[0]), int(degree), coeffs.shape[1], ptr(means), ptr(coeffs),
+                                      cp, ptr(out), self._stream())
         return out
 
     def _check_acc(self, F, d, D):
         if F.dtype != torch.float32 or not F.is_cuda or not F.is_contiguous() or tuple(F.shape) != (self.n, D):
             raise GwbpError(f"F must be a contiguous float32 HIP tensor [{self.n},{D}]")
-        if d is not None and (d.dtype != torch.float32 or not d.is_contiguous() or tuple(d.shape) != (self.n,)):
+        if d is not None and (d.dtype != torch.float32 or not d.is_cuda or not d.is_contiguous()
+                              or tuple(d.shape) != (self.n,)):
             raise GwbpError(f"d must be a contiguous float32 HIP tensor [{self.n}]")
 
     def backproject_view(self, view, means, quats, scales, opacities, feats, F, d, scale_f=1.0, scale_d=1.0):
@@ -267,25 +286,25 @@ class Engine:
         self._check_acc(F, d, D)
         means, quats = _req(means, "means", (3,)), _req(quats, "quats", (4,))
         scales, opacities = _req(scales, "scales", (3,)), _req(opacities, "opacities")
-        check(self.lib.gwbp_backproject_view(*self._args(), C.byref(view), ptr(means), ptr(quats), ptr(scales),
+        self._halves = self._wide_requested()
+        self._call("gwbp_backproject_view", *self._args(), C.byref(view), ptr(means), ptr(quats), ptr(scales),
                                              ptr(opacities), ptr(feats), C.c_int64(sy), C.c_int64(sx),
                                              C.c_int64(sc), D, C.c_float(scale_f), C.c_float(scale_d), ptr(F),
-                                             ptr(d), self._stream()), "gwbp_backproject_view")
+                                             ptr(d), self._stream())
 
     def finalize(self, F, d, out=None):
         out = torch.empty_like(F) if out is None else out
-        check(self.lib.gwbp_finalize(C.c_int64(F.shape[0]), F.shape[1], ptr(F), ptr(d), ptr(out), self._stream()),
-              "gwbp_finalize")
+        self._call("gwbp_finalize", C.c_int64(F.shape[0]), F.shape[1], ptr(F), ptr(d), ptr(out), self._stream())
         return out
 
     # ---- counters ----------------------------------------------------------------------------------------
     def accumulate_stats(self, accum: torch.Tensor):
         """accum: uint8[32] device tensor holding a gwbp_stats struct (zero-initialised by the caller)."""
-        check(self.lib.gwbp_accumulate_stats(*self._args(), ptr(accum), self._stream()), "gwbp_accumulate_stats")
+        self._call("gwbp_accumulate_stats", *self._args(), ptr(accum), self._stream())
 
     def stats(self) -> Dict[str, int]:
         st = Stats()
-        check(self.lib.gwbp_read_stats(*self._args(), C.byref(st), self._stream()), "gwbp_read_stats")
+        self._call("gwbp_read_stats", *self._args(), C.byref(st), self._stream())
         return st.as_dict()
 
     @staticmethod
@@ -300,7 +319,7 @@ class Engine:
         pix = torch.empty(cap, dtype=torch.int32, device=self.device)
         w = torch.empty(cap, device=self.device)
         n = C.c_int64(0)
-        check(self.lib.gwbp_dump_pairs(*self._args(), C.byref(view), C.c_int64(cap), ptr(gid), ptr(pix), ptr(w),
-                                       C.byref(n), self._stream()), "gwbp_dump_pairs")
+        self._call("gwbp_dump_pairs", *self._args(), C.byref(view), C.c_int64(cap), ptr(gid), ptr(pix), ptr(w),
+                                       C.byref(n), self._stream())
         k = int(n.value)
         return gid[:k], pix[:k], w[:k]

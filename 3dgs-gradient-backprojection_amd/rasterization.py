@@ -11,7 +11,6 @@ Backward = scatter with v_render_colors as the feature map: colors.grad[g,:] += 
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -114,7 +113,8 @@ class LazyMeta(dict):
             n = h["stats"]["n_isect"]
             remap = torch.full((p["radii"].shape[0],), -1, dtype=torch.int64, device=vis.device)
             remap[vis] = torch.arange(vis.numel(), device=vis.device) + base
-            isect.append(b["isect_ids"][:n] | (c << 32 + max(1, math.ceil(math.log2(max(2, b["tile_offsets"].numel() - 1))))))
+            # gsplat packs camera | tile | depth with floor(log2(n_tiles)) + 1 tile bits
+            isect.append(b["isect_ids"][:n] | (c << 32 + int(b["tile_offsets"].numel() - 1).bit_length()))
             flat.append(remap[b["flatten_ids"][:n].long()].to(torch.int32))
             offs.append(b["tile_offsets"][:-1] + sum(x.numel() for x in flat[:-1]))
             base += vis.numel()
@@ -140,35 +140,6 @@ class LazyMeta(dict):
 
     def __contains__(self, k):
         return k in self._LAZY or dict.__contains__(self, k)
-
-
-# Real SH basis constants (degree <= 3), as used by every 3DGS implementation.
-_C0 = 0.28209479177387814
-_C1 = 0.4886025119029199
-_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
-_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
-       1.445305721320277, -0.5900435899266435)
-
-
-def spherical_harmonics(degree: int, dirs: torch.Tensor, coeffs: torch.Tensor) -> torch.Tensor:
-    """[N,K,3] SH coefficients -> [N,3] colours for unit `dirs` (host-side torch plumbing; feeds the 2-D
-    feature network in the reference, backproject.py:89-100 -- outside the measured hot path)."""
-    d = dirs / dirs.norm(dim=-1, keepdim=True).clamp_min(1e-12)
-    x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
-    out = _C0 * coeffs[:, 0]
-    if degree >= 1:
-        out = out + _C1 * (-y * coeffs[:, 1] + z * coeffs[:, 2] - x * coeffs[:, 3])
-    if degree >= 2:
-        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
-        out = out + _C2[0] * xy * coeffs[:, 4] + _C2[1] * yz * coeffs[:, 5] + _C2[2] * (2 * zz - xx - yy) * coeffs[:, 6] \
-            + _C2[3] * xz * coeffs[:, 7] + _C2[4] * (xx - yy) * coeffs[:, 8]
-        if degree >= 3:
-            out = out + _C3[0] * y * (3 * xx - yy) * coeffs[:, 9] + _C3[1] * xy * z * coeffs[:, 10] \
-                + _C3[2] * y * (4 * zz - xx - yy) * coeffs[:, 11] \
-                + _C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * coeffs[:, 12] \
-                + _C3[4] * x * (4 * zz - xx - yy) * coeffs[:, 13] + _C3[5] * z * (xx - yy) * coeffs[:, 14] \
-                + _C3[6] * x * (xx - 3 * yy) * coeffs[:, 15]
-    return out
 
 
 def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, near_plane: float = 0.01,

@@ -38,7 +38,12 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--pool", type=int, default=4, help="feature maps cycled through (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-views", type=int, default=1)
+    ap.add_argument("--cpu-views", type=int, default=3, help="views of the workload the CPU baseline is timed on")
+    ap.add_argument("--scatter", choices=("auto", "wide", "narrow"), default="auto",
+                    help="scatter kernel for D %% 256 == 0: auto = chosen from the warm-up views' counters")
+    ap.add_argument("--pipe-wgs", type=int, default=None, help="persistent scatter workgroups (tuning)")
+    ap.add_argument("--side-prio", type=int, default=-1, help="HIP priority of the front stage's stream")
+    ap.add_argument("--no-check", action="store_true", help="skip the post-run result check (the `checked` object)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
     ap.add_argument("--exact-binning", action="store_true",
                     help="gsplat's 3-sigma tile binning instead of GWBP_FLAG_TIGHT_BINNING (same F and d either way)")
@@ -81,8 +86,7 @@ def main():
     pool = [syn.make_feature_map(cfg, 1000 * rank + i, device=dev) for i in range(args.pool)]
     tight = not args.exact_binning
     eng = gsbp_amd.Engine(N, W, H, device=dev, tight_binning=tight)
-    F = torch.zeros(N, D, device=dev)
-    d = torch.zeros(N, device=dev)
+    F, d, F_store = gsbp_amd.backproject.alloc_accumulators(N, D, dev, world)
     my_views = [rank + world * i for i in range(args.steps + args.warmup)]
     views = [eng.view(vms[v], K, W, H) for v in my_views]
 
@@ -94,12 +98,14 @@ def main():
         if not st["overflow"]:
             break
         eng.grow(st)
+    allow_wide = args.scatter != "narrow"
     if args.serial:
-        eng.set_narrow_scatter(not (D % 256 == 0 and "GWBP_NO_WIDE" not in os.environ))
+        eng.set_narrow_scatter(not (D % 256 == 0 and allow_wide))
         pipe, accum = None, torch.zeros(32, dtype=torch.uint8, device=dev)
     else:
         eng2 = gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap, tight_binning=tight)
-        pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng, eng2], scatter_dim=D)
+        pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng, eng2], scatter_dim=D, allow_wide=allow_wide,
+                                     scatter_workgroups=args.pipe_wgs, side_priority=args.side_prio)
         accum = pipe.accum
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
@@ -136,18 +142,26 @@ def main():
         timed = 0 <= k < args.steps
         pipe.scatter(feats, F, d, t0=ev[k][2] if timed else None, t1=ev[k][3] if timed else None)
 
-    front(0)
-    for i in range(args.warmup):
-        front(i + 1)
-        scatter(i)
+    def run_views(lo, hi):
+        """Views lo..hi-1 through the two-deep pipeline; every front and every scatter of the range is enqueued here."""
+        if lo >= hi:
+            return
+        front(lo)
+        for i in range(lo, hi):
+            if i + 1 < hi:
+                front(i + 1)
+            scatter(i)
+
+    run_views(0, args.warmup)
     torch.cuda.synchronize(dev)
     scatter_choice = "narrow"
     if not args.serial:  # the warm-up views' counters pick the scatter kernel (256- or 128-channel) for the timed ones
         st_w = gsbp_amd.Engine.decode_stats(accum)
-        scatter_choice = pipe.choose_scatter_kernel(st_w["n_pairs"], st_w["n_headers"])
-    elif D % 256 == 0 and "GWBP_NO_WIDE" not in os.environ:
+        scatter_choice = pipe.choose_scatter_kernel(*((st_w["n_pairs"], st_w["n_headers"]) if args.scatter == "auto"
+                                                      else (None, None)))
+    elif D % 256 == 0 and allow_wide:
         scatter_choice = "wide"  # serial schedule: the faster kernel alone (set before the warm-up), no priority
-    F.zero_()
+    F_store.zero_()
     d.zero_()
     accum.zero_()
 
@@ -157,20 +171,23 @@ def main():
         torch.cuda.synchronize(dev)
 
     if use_dist:  # first use of each collective (communicator channels, staging buffers) stays outside the timed region
-        wf = torch.zeros(world * 8, D, device=dev)
-        gsbp_amd.reduce_partials_sharded(wf, torch.zeros(world * 8, device=dev))
+        wf, wd, ws = gsbp_amd.backproject.alloc_accumulators(world * 8, D, dev, world)
+        gsbp_amd.reduce_partials_sharded(wf, wd, ws)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_total):
-        if i + 1 < n_total:
-            front(i + 1)
-        scatter(i)
+    run_views(args.warmup, n_total)  # the whole of every timed view, its front stage included, lies in the region
+    F_rows, d_sum, row0 = F, d, 0
     if use_dist:
         # the path's one exchange step, inside the timed region: reduce-scatter of F (rank r keeps the rows it would
         # finalise), all-reduce of d
-        F_rows, d_rows, row0 = gsbp_amd.reduce_partials_sharded(F, d)
+        F_rows, d_sum, row0 = gsbp_amd.reduce_partials_sharded(F, d, F_store)
     barrier()
     elapsed = time.perf_counter() - t0
+
+    checked = None
+    if not args.no_check:
+        checked = check_results(args, gsbp_amd, eng, views, (means, quats, scales, opac), pool, encoder, F_rows, d_sum,
+                                row0, use_dist, dist, dev)
 
     stats = gsbp_amd.Engine.decode_stats(accum)
     tt = torch.tensor([elapsed, float(stats["n_pairs"]), float(stats["overflow"])], dtype=torch.float64, device=dev)
@@ -183,8 +200,7 @@ def main():
     else:
         total_pairs, overflow = float(tt[1]), float(tt[2])
 
-    # front(k) of the first timed view was enqueued during warm-up; its events are not recorded
-    fr = [e[0].elapsed_time(e[1]) for e in ev[1:]] if (not args.serial and args.steps > 1) else [0.0]
+    fr = [e[0].elapsed_time(e[1]) for e in ev] if not args.serial else [0.0]
     t_front = sum(fr) / len(fr)
     t_scatter = sum(e[2].elapsed_time(e[3]) for e in ev) / args.steps
 
@@ -198,11 +214,15 @@ def main():
         b_scatter = 4.0 * H * W * D + 8.0 * n_vis * (D + 1)
         b_view = b_scatter + 44.0 * N + 24.0 * n_isect
         achieved = b_scatter / (t_scatter * 1e-3) / 1e9
-        traffic = None
+        # PMC counters cannot be collected from inside this process: `traffic` is the HBM byte count per launch of the
+        # SAME kernel and workload from the committed rocprofv3 --pmc passes (tools/profile_round.sh, separate runs)
+        traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.config, {}).get("scatter_hbm_bytes_per_launch")
+                tj = json.load(open(tfile)).get(args.config, {})
+                traffic = tj.get("scatter_hbm_bytes_per_launch")
+                traffic_source = "profiles/traffic.json (" + str(tj.get("source", "rocprofv3 --pmc, earlier run")) + ")"
             except Exception:
                 traffic = None
         scatter_kernel = ("k_scatter_wide" if scatter_choice == "wide" else
@@ -224,6 +244,7 @@ def main():
                                     "scatter": t_scatter}},
             "roofline": {"bound": "hbm", "kernel": scatter_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": b_scatter, "launch_ms": t_scatter,
                          "pipeline_achieved_GBs": b_view / (elapsed / args.steps) / 1e9,
                          # second ceiling of the same kernel: fp32 atomics execute memory-side at ~1.3 TB/s of added
@@ -232,6 +253,7 @@ def main():
                          "atomic_peak_GBs": 1300.0,
                          "atomic_frac": n_hdr * (D + 1) * 4.0 / (t_scatter * 1e-3) / 1e9 / 1300.0},
         }
+        out["checked"] = checked
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder,
                                                args.cpu_views)
@@ -250,6 +272,57 @@ def main():
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)
+
+
+def check_results(args, gsbp_amd, eng, views, g, pool, encoder, F_rows, d_sum, row0, use_dist, dist, dev):
+    """Outside the timed region: is what the timed region left in F and d right?
+
+    A second pass over the SAME timed views on ONE stream through a different kernel path -- D = 1 probe maps
+    s_v[p] = feats_v[p,:] . u (u a fixed random unit vector) scattered by the small-D kernel, whose chunk 0 also sums
+    the denominators itself -- gives G[g] = sum_v sum_p w s_v[p] and d'[g] for every Gaussian; linearity of the
+    scatter in the map makes F u == G.  Checks: (1) every row of F u against G, (2) every d against d', (3) weight
+    conservation sum_g d[g] == sum_v sum_p alpha_v[p] (w telescopes per pixel; the alpha map comes out of the blend
+    kernel, not out of the weight store).  Tolerance 1e-4 relative (north_star), per row."""
+    import torch
+    n, D = d_sum.shape[0], F_rows.shape[1]
+    gen = torch.Generator(device=dev).manual_seed(4242)
+    u = torch.randn(D, generator=gen, device=dev)
+    u /= u.norm()
+    probes = [((p if encoder is None else p @ encoder) @ u)[..., None].contiguous() for p in pool]
+    G = torch.zeros(n, 1, device=dev)
+    dG = torch.zeros(n, device=dev)
+    asum = torch.zeros((), dtype=torch.float64, device=dev)
+    eng.set_narrow_scatter(True)
+    eng.set_front_priority(False)
+    for i in range(args.warmup, args.warmup + args.steps):
+        eng.project(views[i], *g)
+        eng.bin_sort(views[i])
+        alphas = eng.blend_weights(views[i], want_alphas=True)
+        eng.scatter(views[i], probes[i % args.pool], G, dG)
+        asum += alphas.double().sum()
+    st = eng.stats()
+    if use_dist:
+        for t in (G, dG, asum):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    rows = slice(row0, row0 + F_rows.shape[0])
+    Fu = F_rows @ u
+    fn = F_rows.norm(dim=1)
+    # F u may cancel; the error of either side scales with the row norm
+    scale_f = torch.maximum(fn, 1e-6 * fn.max().clamp_min(1e-30))
+    err_f = float(((Fu - G[rows, 0]).abs() / scale_f).max())
+    scale_d = torch.maximum(dG, 1e-6 * dG.max().clamp_min(1e-30))
+    err_d = float(((d_sum - dG).abs() / scale_d).max())
+    tot_d, tot_a = float(d_sum.double().sum()), float(asum)
+    err_c = abs(tot_d - tot_a) / max(tot_a, 1e-30)
+    ok = bool(err_f <= 1e-4 and err_d <= 1e-4 and err_c <= 1e-4 and st["overflow"] == 0 and tot_a > 0)
+    if use_dist:
+        okt = torch.tensor([1.0 if ok else 0.0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item() > 0.5)
+    return {"ok": ok, "F_probe_max_rel_err": err_f, "d_max_rel_err": err_d, "conservation_rel_err": err_c,
+            "tolerance": 1e-4,
+            "method": "second serial pass over the timed views: D=1 probe maps feats.u through the small-D scatter "
+                      "kernel (F u == G per row, d == d' per Gaussian) + sum(d) == sum of the blend's alpha maps"}
 
 
 def cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder, n_views):

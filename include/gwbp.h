@@ -12,7 +12,10 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name ends in _host; fp32 arrays are dense row-major
  *   - the caller owns every buffer, including the workspace; the library allocates nothing persistent and
- *     keeps no global mutable state except a thread-local last-error string
+ *     keeps no global mutable state except a thread-local last-error string and two per-device-ordinal caches of
+ *     device facts (CU count; "dynamic-LDS limit raised for kernel k") -- work is launched on the CURRENT HIP device,
+ *     which must be the device of `stream` and of every pointer
+ *   - no environment variable is read (ablation knobs exist only in a -DGWBP_PROFILE build, `make PROFILE=1`)
  *   - every entry point only ENQUEUES work on `stream` (no host synchronisation) unless documented
  *   - return value: 0 = ok, <0 = GWBP_E* (invalid argument / workspace too small), >0 = hipError_t
  *   - quats are (w,x,y,z) and need not be normalised; scales/opacities are post-activation
@@ -84,8 +87,11 @@ typedef struct gwbp_stats {
     uint32_t n_visible;   /* Gaussians surviving projection culling */
     uint32_t n_headers;   /* (Gaussian, tile) pairs with at least one contributing pixel */
     uint32_t pool_used;   /* weight-pool entries a uniform shard capacity would need: kShards x fullest shard */
-    uint32_t overflow;    /* bit0: isect_cap exceeded, bit1: pair_cap exceeded -> results of this view invalid */
-    uint32_t reserved;
+    uint32_t overflow;    /* bit0: isect_cap exceeded, bit1: pair_cap exceeded -> results of this view invalid;
+                           * bit2: gwbp_scatter / gwbp_accumulate_d asked for the 256-channel kernel on a view that was
+                           * blended WITH GWBP_FLAG_NARROW_SCATTER (no half-tile lists / weight sums): that call left
+                           * F and d untouched -- scatter again with the flag set */
+    uint32_t reserved;    /* 1 once gwbp_blend_weights has written the half-tile lists of this view */
 } gwbp_stats;
 
 /* Library / build identification ("gfx950;<git-less build tag>"). */

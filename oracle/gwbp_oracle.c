@@ -229,31 +229,59 @@ int64_t orc_count_isects(int64_t N, const int32_t *radii, const int32_t *rect)
     return n;
 }
 
+/* Stable LSD radix sort of (key, value) pairs, 11-bit digits, parallel over contiguous chunks with per-thread
+ * histograms (a stable sort's result does not depend on the digit width or on the thread count). */
+#define ORC_RADIX_BITS 11
+#define ORC_RADIX (1 << ORC_RADIX_BITS)
 static int radix_sort_pairs(int64_t n, uint64_t *keys, int32_t *vals, int key_bits)
 {
+#ifdef _OPENMP
+    int nt = omp_get_max_threads();
+#else
+    int nt = 1;
+#endif
+    if (nt > 256)
+        nt = 256;
+    if (n < 65536)
+        nt = 1;
     uint64_t *k2 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
     int32_t *v2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
-    int64_t *hist = (int64_t *)malloc(sizeof(int64_t) * 65536);
+    int64_t *hist = (int64_t *)malloc(sizeof(int64_t) * ORC_RADIX * (size_t)nt);
     if (!k2 || !v2 || !hist) {
         free(k2), free(v2), free(hist);
         return ORC_ENOMEM;
     }
     uint64_t *src = keys, *dst = k2;
     int32_t *vs = vals, *vd = v2;
-    for (int shift = 0; shift < key_bits; shift += 16) {
-        memset(hist, 0, sizeof(int64_t) * 65536);
-        for (int64_t i = 0; i < n; ++i)
-            hist[(src[i] >> shift) & 0xFFFF]++;
-        int64_t run = 0;
-        for (int b = 0; b < 65536; ++b) {
-            int64_t c = hist[b];
-            hist[b] = run;
-            run += c;
-        }
-        for (int64_t i = 0; i < n; ++i) {
-            int64_t pos = hist[(src[i] >> shift) & 0xFFFF]++;
-            dst[pos] = src[i];
-            vd[pos] = vs[i];
+    for (int shift = 0; shift < key_bits; shift += ORC_RADIX_BITS) {
+        memset(hist, 0, sizeof(int64_t) * ORC_RADIX * (size_t)nt);
+#pragma omp parallel num_threads(nt)
+        {
+#ifdef _OPENMP
+            const int t = omp_get_thread_num();
+#else
+            const int t = 0;
+#endif
+            const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
+            int64_t *h = hist + (size_t)t * ORC_RADIX;
+            for (int64_t i = i0; i < i1; ++i)
+                h[(src[i] >> shift) & (ORC_RADIX - 1)]++;
+#pragma omp barrier
+#pragma omp single
+            {
+                int64_t run = 0;
+                for (int b = 0; b < ORC_RADIX; ++b)
+                    for (int u = 0; u < nt; ++u) {
+                        const int64_t c = hist[(size_t)u * ORC_RADIX + b];
+                        hist[(size_t)u * ORC_RADIX + b] = run;
+                        run += c;
+                    }
+            } /* implicit barrier */
+            for (int64_t i = i0; i < i1; ++i) {
+                const int64_t pos = h[(src[i] >> shift) & (ORC_RADIX - 1)]++;
+                dst[pos] = src[i];
+                vd[pos] = vs[i];
+            }
         }
         uint64_t *tk = src;
         src = dst, dst = tk;
@@ -272,23 +300,35 @@ int orc_bin_sort(int64_t N, const float *depths, const int32_t *radii, const int
                  int tile_h, int64_t n_isect, int64_t *isect_ids, int32_t *flatten_ids,
                  int32_t *tile_offsets /* [tile_h*tile_w + 1] */)
 {
+    /* emit in (Gaussian, tile row, tile column) order: exclusive scan of the rectangle areas, then a parallel fill */
+    int64_t *start = (int64_t *)malloc(sizeof(int64_t) * (size_t)(N + 1));
+    if (!start)
+        return ORC_ENOMEM;
     int64_t k = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        start[i] = k;
+        if (radii[i] > 0)
+            k += (int64_t)(rect[4 * i + 2] - rect[4 * i]) * (rect[4 * i + 3] - rect[4 * i + 1]);
+    }
+    start[N] = k;
+    if (k != n_isect) {
+        free(start);
+        return ORC_EINVAL;
+    }
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; ++i) {
         if (radii[i] <= 0)
             continue;
         uint32_t dbits;
         memcpy(&dbits, &depths[i], 4);
+        int64_t j = start[i];
         for (int ty = rect[4 * i + 1]; ty < rect[4 * i + 3]; ++ty)
-            for (int tx = rect[4 * i]; tx < rect[4 * i + 2]; ++tx) {
-                if (k >= n_isect)
-                    return ORC_EINVAL;
-                isect_ids[k] = (int64_t)(((uint64_t)(ty * tile_w + tx) << 32) | dbits);
-                flatten_ids[k] = (int32_t)i;
-                ++k;
+            for (int tx = rect[4 * i]; tx < rect[4 * i + 2]; ++tx, ++j) {
+                isect_ids[j] = (int64_t)(((uint64_t)(ty * tile_w + tx) << 32) | dbits);
+                flatten_ids[j] = (int32_t)i;
             }
     }
-    if (k != n_isect)
-        return ORC_EINVAL;
+    free(start);
     int tile_bits = 0;
     while ((1 << tile_bits) < tile_w * tile_h)
         ++tile_bits;
@@ -402,14 +442,19 @@ int64_t orc_blend_pairs(int W, int H, int tile_size, const int32_t *tile_offsets
  * feats is addressed as feats[y*fs_y + x*fs_x + c*fs_c] (strides in floats).
  * acc_double = 1: F is double[N*D], d is double[N]   (parity tests; "exact" sums)
  * acc_double = 0: F is float[N*D],  d is float[N]    (CPU baseline timing; fp32 like the reference)
- * Threads: phase 1 blends tiles of one tile row in parallel; phase 2 splits the channel range across
- * threads so that no two threads touch the same F element (bitwise reproducible, no atomics).
+ * row_of (optional, int32[N]): Gaussian g accumulates into row row_of[g] of F and d; row_of[g] < 0 = not
+ *   wanted (its pairs are still blended and counted).  Lets a test check a subset of the rows of a scene whose
+ *   full F would not fit the host (C4: 5 M x 768).
+ * Threads: the image is processed in bands of tile rows.  Phase 1 blends the band's tiles in parallel; the band's
+ * pairs are then partitioned by OWNER thread (gid % threads) with a stable counting sort, and in phase 2 every
+ * thread accumulates the full channel range of the Gaussians it owns.  Each F element is summed by one thread in
+ * (tile row, tile column, pixel, list slot) order whatever the thread count: bitwise reproducible, no atomics.
  * ---------------------------------------------------------------------------------------------- */
 int orc_blend_scatter(int64_t N, int D, int W, int H, int tile_size, const int32_t *tile_offsets,
                       const int32_t *flatten_ids, const float *means2d, const float *conics,
                       const float *opacities, const float *feats, int64_t fs_y, int64_t fs_x,
                       int64_t fs_c, int acc_double, void *F, void *d, float *alphas, int64_t *n_pairs,
-                      int nthreads)
+                      int nthreads, const int32_t *row_of)
 {
     (void)N;
     const int tile_w = (W + tile_size - 1) / tile_size, tile_h = (H + tile_size - 1) / tile_size;
@@ -420,72 +465,111 @@ int orc_blend_scatter(int64_t N, int D, int W, int H, int tile_size, const int32
 #else
     nthreads = 1;
 #endif
-    pairvec_t *pvs = (pairvec_t *)calloc((size_t)tile_w, sizeof(pairvec_t));
-    if (!pvs)
+    const int nt = nthreads;
+    const int band_rows = 8;
+    const int nb_max = band_rows * tile_w;
+    pairvec_t *pvs = (pairvec_t *)calloc((size_t)nb_max, sizeof(pairvec_t));
+    int64_t *cnt = (int64_t *)malloc(sizeof(int64_t) * (size_t)nb_max * (size_t)nt);
+    int64_t *own = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nt + 1));
+    orc_pair_t *sorted = NULL;
+    int64_t sorted_cap = 0;
+    if (!pvs || !cnt || !own) {
+        free(pvs), free(cnt), free(own);
         return ORC_ENOMEM;
+    }
     int err = 0;
     int64_t total = 0;
-    for (int ty = 0; ty < tile_h && !err; ++ty) {
+    for (int ty0 = 0; ty0 < tile_h && !err; ty0 += band_rows) {
+        const int rows = (ty0 + band_rows <= tile_h) ? band_rows : tile_h - ty0;
+        const int nb = rows * tile_w;
+        /* phase 1: blend, count pairs per (tile, owner) */
 #pragma omp parallel for schedule(dynamic, 1)
-        for (int tx = 0; tx < tile_w; ++tx) {
-            pvs[tx].n = 0;
-            int rc = blend_tile(tx, ty, W, H, tile_size, tile_offsets, tile_w, flatten_ids, means2d, conics,
-                                opacities, &pvs[tx], alphas);
+        for (int i = 0; i < nb; ++i) {
+            pvs[i].n = 0;
+            int rc = blend_tile(i % tile_w, ty0 + i / tile_w, W, H, tile_size, tile_offsets, tile_w, flatten_ids,
+                                means2d, conics, opacities, &pvs[i], alphas);
             if (rc) {
 #pragma omp atomic write
                 err = rc;
             }
+            int64_t *c = cnt + (size_t)i * nt;
+            memset(c, 0, sizeof(int64_t) * (size_t)nt);
+            for (int64_t k = 0; k < pvs[i].n; ++k)
+                c[pvs[i].p[k].gid % nt]++;
         }
         if (err)
             break;
-        for (int tx = 0; tx < tile_w; ++tx)
-            total += pvs[tx].n;
-#pragma omp parallel num_threads(nthreads)
+        /* owner-major, tile-minor exclusive scan: a stable partition that keeps (tile, pair) order inside an owner */
+        int64_t run = 0;
+        for (int o = 0; o < nt; ++o) {
+            own[o] = run;
+            for (int i = 0; i < nb; ++i) {
+                const int64_t c = cnt[(size_t)i * nt + o];
+                cnt[(size_t)i * nt + o] = run;
+                run += c;
+            }
+        }
+        own[nt] = run;
+        total += run;
+        if (run > sorted_cap) {
+            free(sorted);
+            sorted_cap = run + run / 4 + 1024;
+            sorted = (orc_pair_t *)malloc(sizeof(orc_pair_t) * (size_t)sorted_cap);
+            if (!sorted) {
+                err = ORC_ENOMEM;
+                break;
+            }
+        }
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int i = 0; i < nb; ++i) {
+            int64_t *o = cnt + (size_t)i * nt;
+            for (int64_t k = 0; k < pvs[i].n; ++k)
+                sorted[o[pvs[i].p[k].gid % nt]++] = pvs[i].p[k];
+        }
+        /* phase 2: every thread accumulates the Gaussians it owns, all channels */
+#pragma omp parallel num_threads(nt)
         {
 #ifdef _OPENMP
-            const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+            const int tid = omp_get_thread_num();
 #else
-            const int tid = 0, nt = 1;
+            const int tid = 0;
 #endif
-            /* channel slice of this thread, in multiples of 16 channels where possible */
-            const int blocks = (D + 15) / 16;
-            const int b0 = (int)((int64_t)blocks * tid / nt), b1 = (int)((int64_t)blocks * (tid + 1) / nt);
-            const int c0 = b0 * 16, c1 = (b1 * 16 < D) ? b1 * 16 : D;
-            for (int tx = 0; tx < tile_w; ++tx) {
-                const pairvec_t *pv = &pvs[tx];
-                for (int64_t k = 0; k < pv->n; ++k) {
-                    const int32_t g = pv->p[k].gid, pix = pv->p[k].pix;
-                    const float w = pv->p[k].w;
-                    const float *fp = feats + (int64_t)(pix / W) * fs_y + (int64_t)(pix % W) * fs_x;
-                    if (acc_double) {
-                        double *Fg = (double *)F + (int64_t)g * D;
-                        const double wd = (double)w;
-                        if (fs_c == 1)
-                            for (int c = c0; c < c1; ++c)
-                                Fg[c] += wd * (double)fp[c];
-                        else
-                            for (int c = c0; c < c1; ++c)
-                                Fg[c] += wd * (double)fp[(int64_t)c * fs_c];
-                        if (tid == 0)
-                            ((double *)d)[g] += wd;
-                    } else {
-                        float *Fg = (float *)F + (int64_t)g * D;
-                        if (fs_c == 1)
-                            for (int c = c0; c < c1; ++c)
-                                Fg[c] += w * fp[c];
-                        else
-                            for (int c = c0; c < c1; ++c)
-                                Fg[c] += w * fp[(int64_t)c * fs_c];
-                        if (tid == 0)
-                            ((float *)d)[g] += w;
-                    }
+            for (int64_t k = own[tid]; k < own[tid + 1]; ++k) {
+                const int32_t pix = sorted[k].pix;
+                int64_t g = sorted[k].gid;
+                if (row_of) {
+                    g = row_of[g];
+                    if (g < 0)
+                        continue;
+                }
+                const float w = sorted[k].w;
+                const float *fp = feats + (int64_t)(pix / W) * fs_y + (int64_t)(pix % W) * fs_x;
+                if (acc_double) {
+                    double *Fg = (double *)F + g * D;
+                    const double wd = (double)w;
+                    if (fs_c == 1)
+                        for (int c = 0; c < D; ++c)
+                            Fg[c] += wd * (double)fp[c];
+                    else
+                        for (int c = 0; c < D; ++c)
+                            Fg[c] += wd * (double)fp[(int64_t)c * fs_c];
+                    ((double *)d)[g] += wd;
+                } else {
+                    float *Fg = (float *)F + g * D;
+                    if (fs_c == 1)
+                        for (int c = 0; c < D; ++c)
+                            Fg[c] += w * fp[c];
+                    else
+                        for (int c = 0; c < D; ++c)
+                            Fg[c] += w * fp[(int64_t)c * fs_c];
+                    ((float *)d)[g] += w;
                 }
             }
         }
     }
-    for (int tx = 0; tx < tile_w; ++tx)
-        free(pvs[tx].p);
-    free(pvs);
+    for (int i = 0; i < nb_max; ++i)
+        free(pvs[i].p);
+    free(pvs), free(cnt), free(own), free(sorted);
     if (n_pairs)
         *n_pairs = total;
     return err;

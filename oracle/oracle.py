@@ -99,8 +99,11 @@ def blend_pairs(proj, bins, opacities, W: int, H: int, tile_size=16, want_alphas
 
 
 def blend_scatter(proj, bins, opacities, feats: np.ndarray, F: np.ndarray, d: np.ndarray, W: int, H: int,
-                  tile_size=16, nthreads: Optional[int] = None, want_alphas=False):
-    """F[N,D] += sum_p w feats[p,:], d[N] += sum_p w.  F/d float64 (exact sums) or float32 (timing)."""
+                  tile_size=16, nthreads: Optional[int] = None, want_alphas=False,
+                  row_of: Optional[np.ndarray] = None):
+    """F[N,D] += sum_p w feats[p,:], d[N] += sum_p w.  F/d float64 (exact sums) or float32 (timing).
+    row_of (int32[N], optional): Gaussian g accumulates into row row_of[g] of F/d, < 0 = skipped (F, d then have as
+    many rows as the subset: full-size checks of scenes whose whole F would not fit the host)."""
     op = _f32(opacities)
     assert feats.dtype == np.float32 and feats.ndim == 3 and feats.shape[:2] == (H, W)
     D = feats.shape[2]
@@ -110,11 +113,14 @@ def blend_scatter(proj, bins, opacities, feats: np.ndarray, F: np.ndarray, d: np
     alphas = np.zeros((H, W), np.float32) if want_alphas else None
     npairs = C.c_int64(0)
     nt = nthreads or (os.cpu_count() or 1)
+    if row_of is not None:
+        row_of = np.ascontiguousarray(row_of, dtype=np.int32)
+        assert row_of.shape == (op.shape[0],) and int(row_of.max()) < F.shape[0]
     rc = lib().orc_blend_scatter(C.c_int64(F.shape[0]), D, W, H, tile_size, _p(bins["tile_offsets"]),
                                  _p(np.ascontiguousarray(bins["flatten_ids"])), _p(proj["means2d"]),
                                  _p(proj["conics"]), _p(op), _p(feats), C.c_int64(fs[0]), C.c_int64(fs[1]),
                                  C.c_int64(fs[2]), int(F.dtype == np.float64), _p(F), _p(d), _p(alphas),
-                                 C.byref(npairs), nt)
+                                 C.byref(npairs), nt, _p(row_of))
     if rc:
         raise RuntimeError(f"orc_blend_scatter failed: {rc}")
     return int(npairs.value), alphas
@@ -148,10 +154,11 @@ def finalize(F: np.ndarray, d: np.ndarray) -> np.ndarray:
     return out
 
 
-def backproject_view(means, quats, scales, opacities, viewmat, K, W, H, feats, F, d, nthreads=None, **kw):
+def backproject_view(means, quats, scales, opacities, viewmat, K, W, H, feats, F, d, nthreads=None, row_of=None,
+                     **kw):
     proj = project(means, quats, scales, viewmat, K, W, H, **kw)
     bins = bin_sort(proj, W, H)
-    npairs, _ = blend_scatter(proj, bins, opacities, feats, F, d, W, H, nthreads=nthreads)
+    npairs, _ = blend_scatter(proj, bins, opacities, feats, F, d, W, H, nthreads=nthreads, row_of=row_of)
     return dict(n_pairs=npairs, n_isect=bins["n_isect"], n_vis=int((proj["radii"] > 0).sum()), proj=proj, bins=bins)
 
 

@@ -95,3 +95,185 @@ def test_wide_and_narrow_scatter_kernels_agree_at_full_size(c2, dev):
     assert float((Fw - Fn).norm(dim=1).max()) <= 2e-5 * scale
     dn, dw = out["narrow"][1], out["wide"][1]
     assert float((dw - dn).abs().max()) <= 2e-5 * float(dn.max())
+
+
+# ---- BASELINE.json configs at their own sizes, through the driver that ships ------------------------------------------
+def _oracle_views(orc, cfg, g_host, vms, K, maps_host, D, rows=None, acc=np.float64):
+    """Oracle accumulators over the given views; rows = int32[N] row map (subset) or None."""
+    n_out = cfg.n_gaussians if rows is None else int(rows.max()) + 1
+    Fr, dr = np.zeros((n_out, D), acc), np.zeros(n_out, acc)
+    pairs = 0
+    for v in range(len(maps_host)):
+        info = orc.backproject_view(*g_host, vms[v].numpy(), K.numpy(), cfg.width, cfg.height, maps_host[v](), Fr, dr,
+                                    row_of=rows)
+        pairs += info["n_pairs"]
+    return Fr, dr, pairs
+
+
+def _spy_pipeline(monkeypatch):
+    """Records which scatter kernel the ViewPipeline chose and that it really ran on two streams."""
+    seen = {"choices": [], "fronts": 0}
+    orig_choose, orig_front = gsbp_amd.ViewPipeline.choose_scatter_kernel, gsbp_amd.ViewPipeline.front
+
+    def choose(self, a, b):
+        r = orig_choose(self, a, b)
+        seen["choices"].append(r)
+        return r
+
+    def front(self, *a, **k):
+        seen["fronts"] += 1
+        assert self.side != torch.cuda.current_stream(self.dev)
+        return orig_front(self, *a, **k)
+
+    monkeypatch.setattr(gsbp_amd.ViewPipeline, "choose_scatter_kernel", choose)
+    monkeypatch.setattr(gsbp_amd.ViewPipeline, "front", front)
+    return seen
+
+
+def test_c2_d512_pipelined_wide_path_against_oracle(dev, orc, monkeypatch):
+    """What bench.py times, checked at its own size: C2 (1M Gaussians, 1600x1060), D = 512 (two 256-channel chunks),
+    three views through create_feature_field(pipeline=True): ViewPipeline on two streams, k_scatter_wide, the
+    denominators added by k_accum_d on the side stream, raised front priority -- against the CPU oracle."""
+    cfg = syn.CONFIGS["C2"]
+    D, V = cfg.feat_dim, 3
+    g_cpu = syn.activate(syn.make_scene(cfg))
+    g = [t.to(dev) for t in g_cpu]
+    vms, K = syn.make_cameras(cfg, n_views=V), syn.intrinsics(cfg)
+    maps = [syn.make_feature_map(cfg, 20 + v, device=dev) for v in range(V)]
+    seen = _spy_pipeline(monkeypatch)
+    out, F, d, st = gsbp_amd.create_feature_field(*g, vms.to(dev), K.to(dev), cfg.width, cfg.height, lambda v: maps[v],
+                                                  D, return_partials=True)
+    assert st["overflow"] == 0 and seen["fronts"] == V and seen["choices"] == ["wide", "wide"]
+    Fr, dr, pairs = _oracle_views(orc, cfg, [t.numpy() for t in g_cpu], vms, K,
+                                  [lambda v=v: maps[v].cpu().numpy() for v in range(V)], D)
+    assert st["n_pairs"] == pairs
+    assert rel_row_err(F.cpu().numpy(), Fr) <= 1e-4
+    assert rel_row_err(d.cpu().numpy()[:, None], dr[:, None]) <= 1e-4
+    assert np.abs(out.cpu().numpy() - orc.finalize(Fr, dr)).max() <= 1e-4
+    # conservation: sum_g d[g] == sum over views and pixels of (1 - T)
+    eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, tight_binning=True)
+    tot_a = 0.0
+    for v in range(V):
+        view = eng.view(vms[v], K, cfg.width, cfg.height)
+        eng.project(view, *g)
+        eng.bin_sort(view)
+        tot_a += float(eng.blend_weights(view, want_alphas=True).double().sum())
+    assert abs(float(d.double().sum()) - tot_a) <= 2e-5 * tot_a
+
+
+def test_c4_full_size_invariants_and_oracle_subset(dev, orc, monkeypatch):
+    """BASELINE.json configs[3]: 5M Gaussians, D = 768 (F = 15.4 GB).  (i) one view of a channel-constant map through
+    the fused call: conservation, F[:, c] == d, no overflow with the default capacities; (ii) wide vs narrow scatter
+    kernel on one view; (iii) three views through the pipelined driver (which switches from the 256- to the
+    128-channel kernel after two views: short records) against the oracle on a 64 k-Gaussian subset of the rows
+    (SURVEY.md 8(d))."""
+    cfg = syn.CONFIGS["C4"]
+    N, D, V = cfg.n_gaussians, cfg.feat_dim, 3
+    g_cpu = syn.activate(syn.make_scene(cfg))
+    g = [t.to(dev) for t in g_cpu]
+    vms, K = syn.make_cameras(cfg, n_views=V), syn.intrinsics(cfg)
+    eng = gsbp_amd.Engine(N, cfg.width, cfg.height, device=dev, tight_binning=True)
+    assert eng.ws_bytes < 40e9  # the default capacities (16 intersections per Gaussian) fit comfortably in 288 GB
+    view = eng.view(vms[0], K, cfg.width, cfg.height)
+    # (i)
+    ones = torch.ones(cfg.height, cfg.width, D, device=dev)
+    F = torch.zeros(N, D, device=dev)
+    d = torch.zeros(N, device=dev)
+    eng.backproject_view(view, *g, ones, F, d)
+    st = eng.stats()
+    assert st["overflow"] == 0 and st["n_visible"] > 3e6 and st["n_pairs"] > 5e7
+    alphas = eng.blend_weights(view, want_alphas=True)
+    tot_d, tot_a = float(d.double().sum()), float(alphas.double().sum())
+    assert abs(tot_d - tot_a) <= 2e-5 * tot_a
+    assert float((F - d[:, None]).abs().max()) <= 1e-4 * float(d.max())
+    del ones, alphas
+    # (ii)
+    feats = syn.make_feature_map(cfg, 31, device=dev)
+    eng.set_narrow_scatter(True)
+    F.zero_(), d.zero_()
+    eng.backproject_view(view, *g, feats, F, d)
+    eng.set_narrow_scatter(False)
+    Fw, dw = torch.zeros_like(F), torch.zeros_like(d)
+    eng.backproject_view(view, *g, feats, Fw, dw)
+    assert eng.stats()["overflow"] == 0
+    scale = float(F.norm(dim=1).max())
+    assert float((Fw - F).norm(dim=1).max()) <= 2e-5 * scale
+    assert float((dw - d).abs().max()) <= 2e-5 * float(d.max())
+    del F, Fw, d, dw, eng
+    torch.cuda.empty_cache()
+    # (iii)
+    maps = [feats] + [syn.make_feature_map(cfg, 32 + v, device=dev) for v in range(1, V)]
+    seen = _spy_pipeline(monkeypatch)
+    out, F, d, st = gsbp_amd.create_feature_field(*g, vms.to(dev), K.to(dev), cfg.width, cfg.height, lambda v: maps[v],
+                                                  D, return_partials=True)
+    # the driver starts wide and re-decides from the counters of views 0 and 1 (C4: short records -> 128-channel kernel)
+    expect = "wide" if st["n_pairs"] / st["n_headers"] >= gsbp_amd.ViewPipeline.WIDE_MIN_PAIRS_PER_RECORD else "narrow"
+    assert st["overflow"] == 0 and seen["choices"] == ["wide", expect]
+    sel = np.arange(0, N, N // 65536)[:65536]
+    rows = np.full(N, -1, np.int32)
+    rows[sel] = np.arange(sel.size, dtype=np.int32)
+    Fr, dr, pairs = _oracle_views(orc, cfg, [t.numpy() for t in g_cpu], vms, K,
+                                  [lambda v=v: maps[v].cpu().numpy() for v in range(V)], D, rows=rows)
+    assert st["n_pairs"] == pairs
+    sel_t = torch.from_numpy(sel).to(dev)
+    assert int((dr > 0).sum()) > 20000  # the subset really sees weight
+    assert rel_row_err(F[sel_t].cpu().numpy(), Fr) <= 1e-4
+    assert rel_row_err(d[sel_t].cpu().numpy()[:, None], dr[:, None]) <= 1e-4
+    assert np.abs(out[sel_t].cpu().numpy() - orc.finalize(Fr, dr)).max() <= 1e-4
+
+
+def test_c5_full_size_encoder_path_against_oracle(dev, orc):
+    """BASELINE.json configs[4] (backproject_compressed.py:127-165): 1M Gaussians, 512 -> 16 encoder, two full-size
+    views through the pipelined driver; the oracle gets the map encoded on the CPU."""
+    cfg = syn.CONFIGS["C5"]
+    V = 2
+    g_cpu = syn.activate(syn.make_scene(cfg))
+    g = [t.to(dev) for t in g_cpu]
+    vms, K = syn.make_cameras(cfg, n_views=V), syn.intrinsics(cfg)
+    enc = syn.make_encoder(cfg)
+    maps = [syn.make_feature_map(cfg, 40 + v, device=dev) for v in range(V)]
+    out, F, d, st = gsbp_amd.create_feature_field(*g, vms.to(dev), K.to(dev), cfg.width, cfg.height, lambda v: maps[v],
+                                                  cfg.feat_dim, encoder=enc.to(dev), return_partials=True)
+    assert st["overflow"] == 0 and tuple(F.shape) == (cfg.n_gaussians, cfg.encoder_dim)
+    Fr, dr, pairs = _oracle_views(orc, cfg, [t.numpy() for t in g_cpu], vms, K,
+                                  [lambda v=v: (maps[v].cpu() @ enc).numpy() for v in range(V)], cfg.encoder_dim)
+    assert st["n_pairs"] == pairs
+    assert rel_row_err(F.cpu().numpy(), Fr) <= 1e-4
+    assert rel_row_err(d.cpu().numpy()[:, None], dr[:, None]) <= 1e-4
+    assert np.abs(out.cpu().numpy() - orc.finalize(Fr, dr)).max() <= 1e-4
+
+
+def test_dino_width_1024_nearest_64x64_mean_reduction(dev, orc):
+    """create_feature_field_dino at its real width (backproject.py:201-210,242-289): D = 1024, a 64x64 patch-token map
+    nearest-upsampled to the view inside the scatter kernel, .mean() reductions; C2 geometry (1M Gaussians), two views,
+    against the oracle fed the materialised F.interpolate(mode="nearest") map, on a 64 k-row subset."""
+    cfg = syn.CONFIGS["C2"]
+    N, D, V = cfg.n_gaussians, 1024, 2
+    g_cpu = syn.activate(syn.make_scene(cfg))
+    g = [t.to(dev) for t in g_cpu]
+    vms, K = syn.make_cameras(cfg, n_views=V), syn.intrinsics(cfg)
+    gen = torch.Generator().manual_seed(77)
+    low = [torch.randn(64, 64, D, generator=gen) for _ in range(V)]
+    low_dev = [t.to(dev) for t in low]
+    out, F, d, st = gsbp_amd.create_feature_field(*g, vms.to(dev), K.to(dev), cfg.width, cfg.height,
+                                                  lambda v: low_dev[v], D, reduction="mean", upsample="nearest",
+                                                  return_partials=True)
+    assert st["overflow"] == 0
+    sel = np.arange(0, N, N // 65536)[:65536]
+    rows = np.full(N, -1, np.int32)
+    rows[sel] = np.arange(sel.size, dtype=np.int32)
+
+    def up(v):  # the reference's own op (backproject.py:244-248)
+        x = low[v].permute(2, 0, 1)[None]
+        return torch.nn.functional.interpolate(x, size=(cfg.height, cfg.width), mode="nearest")[0].permute(1, 2, 0) \
+            .contiguous().numpy()
+
+    Fr, dr, pairs = _oracle_views(orc, cfg, [t.numpy() for t in g_cpu], vms, K, [lambda v=v: up(v) for v in range(V)],
+                                  D, rows=rows)
+    assert st["n_pairs"] == pairs
+    Fr /= float(cfg.height * cfg.width * D)  # backproject.py:263
+    dr /= float(cfg.height * cfg.width * 3)  # backproject.py:283
+    sel_t = torch.from_numpy(sel).to(dev)
+    assert rel_row_err(F[sel_t].cpu().numpy(), Fr) <= 1e-4
+    assert rel_row_err(d[sel_t].cpu().numpy()[:, None], dr[:, None]) <= 1e-4
+    assert np.abs(out[sel_t].cpu().numpy() - orc.finalize(Fr, dr)).max() <= 1e-4
