@@ -10,3 +10,4 @@ from .backproject import ViewPipeline, create_feature_field, finalize_reference,
 from .engine import Engine, bilinear_index, nearest_index  # noqa: F401
 from . import scene_io  # noqa: F401
 from .rasterization import rasterization  # noqa: F401
+from .pruning import check_proper_pruning, gradient_mask, prune_by_gradients  # noqa: F401

@@ -25,7 +25,10 @@ def get_engine(device, n: int, width: int, height: int) -> Engine:
     key = (str(device), n, width, height)
     eng = _ENGINES.get(key)
     if eng is None:
-        for k in [k for k in _ENGINES if k[0] == key[0]]:  # one live workspace per device
+        # at most two live workspaces per device (utils.test_proper_pruning alternates between the full and the pruned
+        # scene, utils.py:316-340); the least recently created one goes first
+        mine = [k for k in _ENGINES if k[0] == key[0]]
+        for k in mine[:max(0, len(mine) - 1)]:
             del _ENGINES[k]
         eng = _ENGINES[key] = Engine(n, width, height, device=device)
         eng.generation = 0

@@ -50,6 +50,18 @@
 #define ORC_T_MIN 0x1.a36e2ep-14f      /* 1e-4 */
 #define ORC_RADIUS_FLOOR 0x1.47ae14p-7f /* 0.01 inside sqrt(max(.,b*b-det)) */
 
+/* Sensitivity knobs (tests/test_sensitivity.py only): the two items of SURVEY.md 3.3's uncertainty register that this
+ * container cannot settle without gsplat's source -- the radius floor inside sqrt(max(floor, b*b - det)) (0.01 here,
+ * 0.1 in the Inria rasteriser) and the last bits of exp() (__expf in the CUDA original is good to ~2 ulp).  Defaults are
+ * the contract; orc_set_tunables(0.01f, 0) restores them. */
+static float g_radius_floor = ORC_RADIUS_FLOOR;
+static int g_exp_ulp = 0;
+void orc_set_tunables(float radius_floor, int exp_ulp)
+{
+    g_radius_floor = radius_floor;
+    g_exp_ulp = exp_ulp;
+}
+
 static inline float dot3f(float a0, float a1, float a2, float b0, float b1, float b2)
 {
     return fmaf(a2, b2, fmaf(a1, b1, a0 * b0));
@@ -75,6 +87,7 @@ static inline float orc_exp_neg(float x)
     int32_t bits;
     memcpy(&bits, &p, 4);
     bits += ((int32_t)n) << 23;
+    bits += g_exp_ulp; /* 0 unless a sensitivity test asked for a perturbed exp */
     memcpy(&p, &bits, 4);
     return p;
 }
@@ -189,7 +202,7 @@ int orc_project(int64_t N, const float *means, const float *quats, const float *
             continue;
         const float inv_det = 1.0f / det;
         const float b = 0.5f * (c00 + c11);
-        const float v1 = b + sqrtf(fmaxf(ORC_RADIUS_FLOOR, b * b - det));
+        const float v1 = b + sqrtf(fmaxf(g_radius_floor, b * b - det));
         const float radf = ceilf(3.f * sqrtf(v1));
         if (!(radf > radius_clip) || !(radf < 1.0e9f))
             continue;
@@ -446,10 +459,12 @@ int64_t orc_blend_pairs(int W, int H, int tile_size, const int32_t *tile_offsets
  *   wanted (its pairs are still blended and counted).  Lets a test check a subset of the rows of a scene whose
  *   full F would not fit the host (C4: 5 M x 768).
  * Threads: the image is processed in bands of tile rows.  Phase 1 blends the band's tiles in parallel; the band's
- * pairs are then partitioned by OWNER thread (gid % threads) with a stable counting sort, and in phase 2 every
+ * pairs are then partitioned by OWNER thread ((gid / 16) % threads) with a stable counting sort, and in phase 2 every
  * thread accumulates the full channel range of the Gaussians it owns.  Each F element is summed by one thread in
  * (tile row, tile column, pixel, list slot) order whatever the thread count: bitwise reproducible, no atomics.
  * ---------------------------------------------------------------------------------------------- */
+/* 16 consecutive Gaussians (one 64-B line of d[]) share an owner thread: no two threads write the same cache line */
+#define ORC_OWNER(gid, nt) (((gid) >> 4) % (nt))
 int orc_blend_scatter(int64_t N, int D, int W, int H, int tile_size, const int32_t *tile_offsets,
                       const int32_t *flatten_ids, const float *means2d, const float *conics,
                       const float *opacities, const float *feats, int64_t fs_y, int64_t fs_x,
@@ -495,7 +510,7 @@ int orc_blend_scatter(int64_t N, int D, int W, int H, int tile_size, const int32
             int64_t *c = cnt + (size_t)i * nt;
             memset(c, 0, sizeof(int64_t) * (size_t)nt);
             for (int64_t k = 0; k < pvs[i].n; ++k)
-                c[pvs[i].p[k].gid % nt]++;
+                c[ORC_OWNER(pvs[i].p[k].gid, nt)]++;
         }
         if (err)
             break;
@@ -524,7 +539,7 @@ int orc_blend_scatter(int64_t N, int D, int W, int H, int tile_size, const int32
         for (int i = 0; i < nb; ++i) {
             int64_t *o = cnt + (size_t)i * nt;
             for (int64_t k = 0; k < pvs[i].n; ++k)
-                sorted[o[pvs[i].p[k].gid % nt]++] = pvs[i].p[k];
+                sorted[o[ORC_OWNER(pvs[i].p[k].gid, nt)]++] = pvs[i].p[k];
         }
         /* phase 2: every thread accumulates the Gaussians it owns, all channels */
 #pragma omp parallel num_threads(nt)

@@ -47,6 +47,11 @@ def _f32(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
 
 
+def set_tunables(radius_floor: float = 0.01, exp_ulp: int = 0) -> None:
+    """Sensitivity knobs of SURVEY.md 3.3's uncertainty register (tests/test_sensitivity.py); no arguments = contract."""
+    lib().orc_set_tunables(C.c_float(radius_floor), C.c_int(exp_ulp))
+
+
 def exp_neg(x: float) -> float:
     return float(lib().orc_exp_neg_export(C.c_float(x)))
 

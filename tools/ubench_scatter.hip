@@ -9,6 +9,16 @@
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
+__device__ __forceinline__ float4 lds_read_b128(unsigned a)
+{
+#if __HIP_DEVICE_COMPILE__
+    return *(const __attribute__((address_space(3))) float4 *)(size_t)a;
+#else
+    (void)a;
+    return float4{};
+#endif
+}
+
 // MODE 0: 2 readlane + lshl_add + ds_read_b64 + pk_fma   (current design)
 // MODE 1: lshl_add + ds_read_b64 + pk_fma with VGPR-held w/pix (no readlane; per-lane values, uniform content)
 // MODE 2: readlanes only (+ trivial use)
@@ -23,7 +33,7 @@ __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ w
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 32768; i += 1024)
         lds[i] = (float)(i & 255) * 1e-3f;
-    for (int i = threadIdx.x; i < 2048; i += 1024) { // per-wave entry tables for modes 6/7
+    for (int i = threadIdx.x; i < 4096 + 256; i += 1024) { // per-wave entry tables for modes 6/7
         lds[32768 + i] = (i & 1) ? __int_as_float((i * 37) & 255) : 0.001f * (i % 97);
     }
     __syncthreads();
@@ -126,6 +136,56 @@ __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ w
                         acc.y = __builtin_fmaf(e4[j].z, f[2 * j + 1].y, acc.y);
                     }
                 }
+            } else if (MODE == 8 || MODE == 9) {
+                // "two pairs per wave-instruction": lanes 0-31 and 32-63 work on DIFFERENT pairs, each half covering 128
+                // channels with 4 channels per lane (slab row = 512 B); {w, pix} come per half from the wave's entry
+                // table in LDS (two distinct addresses per read: broadcast inside a half), no v_readlane.
+                const int h = lane >> 5, s = lane & 31;
+                const char *ent = slab + 131072 + wave * 1024 + (it & 1) * 512; // loop-variant: keeps the reads in the loop
+                const unsigned ent_off = 131072u + wave * 1024u + (it & 1) * 512u + 8u * h; // dynamic LDS starts at 0
+                float4 g[8];
+                if (MODE == 8) {
+                    float2 e[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(e[j]) : "v"(ent_off), "n"(16 * (8 * b + j)));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // asm reads are invisible to hipcc's waitcnt pass
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        unsigned a;
+                        asm volatile("v_lshl_add_u32 %0, %1, 9, %2" : "=v"(a) : "v"(e[j].y), "v"(s * 16));
+                        g[j] = lds_read_b128(a); // dynamic LDS starts at 0
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        acc.x = __builtin_fmaf(e[j].x, g[j].x, acc.x);
+                        acc.y = __builtin_fmaf(e[j].x, g[j].y, acc.y);
+                        acc2.x = __builtin_fmaf(e[j].x, g[j].z, acc2.x);
+                        acc2.y = __builtin_fmaf(e[j].x, g[j].w, acc2.y);
+                    }
+                } else {
+                    float4 e4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        e4[j] = *(const float4 *)(ent + 32 * (4 * b + j) + 16 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int p0 = __float_as_int(e4[j].y), p1 = __float_as_int(e4[j].w);
+                        g[2 * j] = *(const float4 *)(slab + ((p0 << 9) + s * 16));
+                        g[2 * j + 1] = *(const float4 *)(slab + ((p1 << 9) + s * 16));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc.x = __builtin_fmaf(e4[j].x, g[2 * j].x, acc.x);
+                        acc.y = __builtin_fmaf(e4[j].x, g[2 * j].y, acc.y);
+                        acc2.x = __builtin_fmaf(e4[j].x, g[2 * j].z, acc2.x);
+                        acc2.y = __builtin_fmaf(e4[j].x, g[2 * j].w, acc2.y);
+                        acc.x = __builtin_fmaf(e4[j].z, g[2 * j + 1].x, acc.x);
+                        acc.y = __builtin_fmaf(e4[j].z, g[2 * j + 1].y, acc.y);
+                        acc2.x = __builtin_fmaf(e4[j].z, g[2 * j + 1].z, acc2.x);
+                        acc2.y = __builtin_fmaf(e4[j].z, g[2 * j + 1].w, acc2.y);
+                    }
+                }
             } else if (MODE == 5) {
                 float4 g[8];
 #pragma unroll
@@ -149,21 +209,22 @@ __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ w
 }
 
 template <int MODE>
-void run(const char *name, int iters, const float *w, const int *p, float *out)
+void run(const char *name, int iters, const float *w, const int *p, float *out, double chunks_per_group = 1.0)
 {
-    CHECK(hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 8192));
+    CHECK(hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 16384 + 1024));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    k<MODE><<<256, 1024, 131072 + 8192>>>(iters, w, p, out);
+    k<MODE><<<256, 1024, 131072 + 16384 + 1024>>>(iters, w, p, out);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    k<MODE><<<256, 1024, 131072 + 8192>>>(iters, w, p, out);
+    k<MODE><<<256, 1024, 131072 + 16384 + 1024>>>(iters, w, p, out);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
-    const double pairs_per_cu = (double)iters * 64 * 16; // per CU (16 waves)
+    // one loop group = one (pair, 128 channels) unit in modes 0-4, 6, 7; two such units in modes 5, 8, 9
+    const double pairs_per_cu = (double)iters * 64 * 16 * chunks_per_group; // per CU (16 waves)
     printf("%-34s %8.3f ms  %6.2f ns/pair/wave  %5.2f pairs/us/CU  -> C2 view (1.35M pair-chunks/CU): %.2f ms\n", name, ms,
            ms * 1e6 / (iters * 64.0), pairs_per_cu / (ms * 1e3), 1.35e6 / (pairs_per_cu / ms));
 }
@@ -186,8 +247,10 @@ int main()
     run<2>("2 readlanes only", iters, w, p, out);
     run<3>("3 b64 + pkfma only", iters, w, p, out);
     run<4>("4 bpermute x2 + add + b64 + pkfma", iters, w, p, out);
-    run<5>("5 readlane x2 + add + b128 + 2pkfma", iters, w, p, out);
+    run<5>("5 readlane x2 + add + b128 + 2pkfma", iters, w, p, out, 2.0);
     run<6>("6 LDS bcast b64/pair + add+b64+pkfma", iters, w, p, out);
     run<7>("7 LDS bcast b128/2pairs + ...", iters, w, p, out);
+    run<8>("8 2 pairs/instr: b64 ent + add + b128 + 2pkfma", iters, w, p, out, 2.0);
+    run<9>("9 2 pairs/instr: b128 ent/2 steps + ...", iters, w, p, out, 2.0);
     return 0;
 }
