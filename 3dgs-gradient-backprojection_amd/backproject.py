@@ -160,7 +160,7 @@ class ViewPipeline:
 
     def front(self, view, means, quats, scales, opacities, d=None, scale_d=1.0):
         """d (optional): the denominator accumulator.  With the 256-channel scatter kernel chosen, the view's share of d
-        is added right behind the blend on the side stream (gwbp_accumulate_d) and scatter() then leaves d alone: the
+        is added by the blend itself on the side stream (gwbp_blend_weights_d) and scatter() then leaves d alone: the
         denominators cost nothing on the scatter's stream."""
         b = self.i_front % 2
         main = torch.cuda.current_stream(self.dev)
@@ -172,10 +172,8 @@ class ViewPipeline:
             e = self.eng[b]
             e.project(view, means, quats, scales, opacities)
             e.bin_sort(view)
-            e.blend_weights(view)
             d_done = d is not None and self.wide
-            if d_done:
-                e.accumulate_d(view, d, scale_d)
+            e.blend_weights(view, d=d if d_done else None, scale_d=scale_d)
             self.ev_front[b].record(self.side)
         self.pending[self.i_front] = (view, d_done)
         self.i_front += 1

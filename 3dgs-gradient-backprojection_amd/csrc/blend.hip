@@ -32,7 +32,8 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
                                               u32 *__restrict__ hdr_count, WPair *__restrict__ wpool, u32 pair_cap,
                                               u32 *__restrict__ shards, const u32 *__restrict__ tile_order, float *__restrict__ alphas,
                                               HalfHdr *__restrict__ half_a, HalfHdr *__restrict__ half_b,
-                                              u32 *__restrict__ half_cnt_a, u32 *__restrict__ half_cnt_b, int dbg, int prio)
+                                              u32 *__restrict__ half_cnt_a, u32 *__restrict__ half_cnt_b, int dbg, int prio,
+                                              float *__restrict__ d_out, float scale_d)
 {
     front_priority(prio);
     __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
@@ -212,6 +213,10 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
                     h.wsum = (u32)__float_as_int(wsum), h.pad = 0;
                     h.mask[0] = m[0], h.mask[1] = m[1], h.mask[2] = m[2], h.mask[3] = m[3];
                     headers[beg + hdr_n] = h;
+                    if constexpr (HALVES) { // gwbp_blend_weights_d: the record's share of d[gid] right here (no k_accum_d)
+                        if (d_out)
+                            atomicAdd(d_out + h.gid, wsum * scale_d);
+                    }
                     // the same record as (up to) two half-tile visits for k_scatter_wide
                     const u32 ct = HALVES ? cnt[0] + cnt[1] : 0u, cb = HALVES ? cnt[2] + cnt[3] : 0u;
                     const u32 span = (ct != 0 && cb != 0 && n_top < (u32)kCarryRows) ? 0x100u : 0u;
@@ -303,8 +308,10 @@ __global__ void k_pool_stats(const u32 *__restrict__ shards, Counters *__restric
     ctr->pool_head = mx * (u32)kShards;
 }
 
-int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, hipStream_t s)
+int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, float *d, float scale_d, hipStream_t s)
 {
+    if (d && (L.flags & GWBP_FLAG_NARROW_SCATTER))
+        return set_error(GWBP_EINVAL, "gwbp_blend_weights_d needs a blend without GWBP_FLAG_NARROW_SCATTER (no weight sums)");
     const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
     const int n_tiles = V.tile_w * V.tile_h;
     const int fin = sort_passes(n_tiles) & 1;
@@ -314,7 +321,7 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
 #define GWBP_BLEND(H)                                                                                                 \
     hipLaunchKernelGGL(k_blend<H>, dim3(n_tiles), dim3(64), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d,  \
                        W.counters, W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, W.tile_order, alphas,  \
-                       W.half[0], W.half[1], W.half_count[0], W.half_count[1], ablate, prio)
+                       W.half[0], W.half[1], W.half_count[0], W.half_count[1], ablate, prio, d, scale_d)
     if (L.flags & GWBP_FLAG_NARROW_SCATTER)
         GWBP_BLEND(false);
     else

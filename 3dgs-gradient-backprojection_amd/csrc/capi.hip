@@ -287,7 +287,23 @@ int gwbp_blend_weights(const gwbp_caps *caps, void *workspace, size_t workspace_
         return rc;
     if ((rc = make_view(view_host, caps, &V)))
         return rc;
-    return launch_blend(L, W, V, alphas, static_cast<hipStream_t>(stream));
+    return launch_blend(L, W, V, alphas, nullptr, 0.f, static_cast<hipStream_t>(stream));
+}
+
+int gwbp_blend_weights_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                         float *alphas, float scale_d, float *d, void *stream)
+{
+    Layout L;
+    Ws W;
+    ViewDev V;
+    int rc = bind_workspace(caps, workspace, workspace_bytes, &L, &W);
+    if (rc)
+        return rc;
+    if ((rc = make_view(view_host, caps, &V)))
+        return rc;
+    if (!d)
+        return set_error(GWBP_EINVAL, "null d");
+    return launch_blend(L, W, V, alphas, d, scale_d, static_cast<hipStream_t>(stream));
 }
 
 int gwbp_accumulate_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
@@ -421,7 +437,7 @@ int gwbp_backproject_view(const gwbp_caps *caps, void *workspace, size_t workspa
         return rc;
     if ((rc = launch_bin_sort(L, W, V, nullptr, nullptr, nullptr, s)))
         return rc;
-    if ((rc = launch_blend(L, W, V, nullptr, s)))
+    if ((rc = launch_blend(L, W, V, nullptr, nullptr, 0.f, s)))
         return rc;
     const FeatMap M{feats, fs_y, fs_x, fs_c, nullptr, nullptr, nullptr, nullptr, 0, 0};
     return launch_scatter(L, W, V, M, D, scale_f, scale_d, F, d, s);

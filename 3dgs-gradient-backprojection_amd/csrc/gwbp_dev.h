@@ -149,7 +149,7 @@ int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *
 int launch_emit(const Layout &L, const Ws &W, const ViewDev &V, const u32 *order, hipStream_t s);
 int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *isect_ids, int32_t *flatten_ids,
                     int32_t *tile_offsets, hipStream_t s);
-int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, hipStream_t s);
+int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, float *d, float scale_d, hipStream_t s);
 // A 2-D feature map as the scatter kernels address it: feats[row(y)*fs_y + col(x)*fs_x + c*fs_c] (strides in floats).
 // ymap/xmap (device, optional) send an output pixel to the row/column of a lower-resolution map: the
 // F.interpolate(mode="nearest") of backproject.py:244-248 without materialising the upsampled map.  With ly/lx as well

@@ -160,9 +160,20 @@ class Engine:
     def _wide_requested(self) -> bool:
         return not (self.caps.flags & _lib.FLAG_NARROW_SCATTER)
 
-    def blend_weights(self, view, want_alphas=False):
+    def blend_weights(self, view, want_alphas=False, d=None, scale_d=1.0):
+        """d (optional, float32[N]): also add this view's denominators d[g] += scale_d * sum_p w_g(p) from inside the blend
+        (gwbp_blend_weights_d; needs the 256-channel scatter kernel enabled, like accumulate_d)."""
         alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
         self._halves = self._wide_requested()  # k_blend<HALVES> writes the lists only without NARROW_SCATTER
+        if d is not None:
+            if d.dtype != torch.float32 or not d.is_cuda or d.shape != (self.n,) or not d.is_contiguous():
+                raise GwbpError("d must be a contiguous float32 HIP tensor [N]")
+            if not self._halves:
+                raise GwbpError("blend_weights(d=...) needs the 256-channel scatter kernel enabled "
+                                "(set_narrow_scatter(False)): a narrow blend takes no weight sums")
+            self._call("gwbp_blend_weights_d", *self._args(), C.byref(view), ptr(alphas), C.c_float(scale_d), ptr(d),
+                       self._stream())
+            return alphas
         self._call("gwbp_blend_weights", *self._args(), C.byref(view), ptr(alphas), self._stream())
         return alphas
 

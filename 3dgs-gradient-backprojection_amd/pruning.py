@@ -58,7 +58,7 @@ def gradient_mask(splats: Dict[str, torch.Tensor], viewmats: torch.Tensor, K: to
             if not st["overflow"]:
                 break
             eng.grow(st)
-        eng.accumulate_d(view, d)
+        eng.accumulate_d(view, d)  # after the overflow check: a retried view must not be counted twice
     return d > 0
 
 

@@ -120,6 +120,13 @@ int gwbp_bin_sort(const gwbp_caps *caps, void *workspace, size_t workspace_bytes
 int gwbp_blend_weights(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                        float *alphas, void *stream);
 
+/* gwbp_blend_weights that also adds the view's denominators, d[g] += scale_d * sum_p w_g(p), while it writes each
+ * record (needs caps WITHOUT GWBP_FLAG_NARROW_SCATTER): what a caller that overlaps the front stage of view v+1 with
+ * the scatter of view v uses on the front's stream (then d = NULL for gwbp_scatter) -- the whole denominator pass of
+ * backproject.py:133-150 costs one 4-B atomic per (Gaussian, tile) record and no kernel of its own. */
+int gwbp_blend_weights_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                         float *alphas, float scale_d, float *d, void *stream);
+
 /* d[g] += scale_d * sum_p w_g(p) alone, from the per-record weight sums gwbp_blend_weights left in the workspace
  * (needs a blend WITHOUT GWBP_FLAG_NARROW_SCATTER).  A caller that overlaps the front stage of view v+1 with the
  * scatter of view v issues it behind the blend on the front's stream and passes d = NULL to gwbp_scatter: the
