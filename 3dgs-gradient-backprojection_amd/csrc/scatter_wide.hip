@@ -31,6 +31,16 @@
 
 namespace gwbp {
 
+#ifdef GWBP_PROFILE
+// In-kernel stamps (PROFILE build only, tools/stamp_scatter.py): shader cycles summed over the waves of all workgroups,
+// [0] slab staging incl. its barrier, [1] visit loop, [2] drain (s_waitcnt vmcnt(0)), [3] end-of-phase barrier wait,
+// [4] phases, [5] visits.
+__device__ unsigned long long g_wide_prof[8];
+#define GWBP_STAMP(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#else
+#define GWBP_STAMP(x)
+#endif
+
 namespace {
 
 constexpr int kWide = 256;            // channels per chunk
@@ -52,6 +62,17 @@ __device__ __forceinline__ float readlane_f(float v, int l)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 __device__ __forceinline__ u32 readlane_u(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+// 16-B LDS read at a BYTE ADDRESS (the slab is the start of the kernel's only LDS allocation): lets the compiler fold
+// the whole address into one v_lshl_add_u32
+__device__ __forceinline__ float4 lds_read_b128(u32 a)
+{
+#if __HIP_DEVICE_COMPILE__
+    return *reinterpret_cast<const __attribute__((address_space(3))) float4 *>((size_t)a);
+#else
+    (void)a;
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+}
 
 struct EV { // entries 64j .. 64j+63 of a visit, one per lane
     float w;
@@ -112,6 +133,9 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     if (threadIdx.x == 0)
         s_item[0] = atomicAdd(queue, 1u);
     __syncthreads();
+#ifdef GWBP_PROFILE
+    unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
     for (u32 k = 0;; ++k) {
     const u32 item = uniform(s_item[k & 1u]); // wave-uniform by construction: keep every derived address scalar
     if (item >= n_items)
@@ -123,6 +147,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
 
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {
+    GWBP_STAMP(ts0);
     const u32 nh = uniform(phase ? cnt_b[tile] : cnt_a[tile]);
     const HalfHdr *hbase = (phase ? half_b : half_a) + tile_offsets[tile];
     if (threadIdx.x == 0)
@@ -161,9 +186,13 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     if (phase == 0 && threadIdx.x == 0)
         s_item[(k + 1u) & 1u] = nxt;
     __syncthreads();
+    GWBP_STAMP(ts1);
+#ifdef GWBP_PROFILE
+    u32 n_vis_prof = 0;
+#endif
 
-    const u32 lane_base = (u32)(lane * 16);
-    const char *slab = reinterpret_cast<const char *>(lds);
+    // dynamic LDS starts at address 0 (no static __shared__ in this kernel): slab row r lives at byte r * 1024
+    const u32 row_base = (u32)(lane * 16) - (phase ? (u32)(kHalfPix << 10) : 0u);
 
     auto claim = [&]() __attribute__((always_inline)) -> u32 {
         u32 h = 0;
@@ -203,14 +232,18 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         // pipeline degenerates to the serial schedule.  At 83 VGPRs the front runs beside it as with k_scatter_full.
         constexpr int kB = 8;
         float4 f[kB];
-#define GWBP_ISSUE8(B)                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                    \
+        // LDS address = slab row of the pixel + this lane's 16 B: ONE v_lshl_add_u32 per pair straight from the
+        // v_readlane'd pixel index (no scalar mask/shift: row_base already carries -128 rows in the bottom pass, where
+        // every real entry has pix >= 128; the {0, 0} padding entries then point below the slab -- an out-of-range LDS
+        // read returns 0 and their weight is 0 anyway).
+#define GWBP_ISSUE(B, J0, J1)                                                                                         \
+    _Pragma("unroll") for (int j = J0; j < J1; ++j)                                                                   \
     {                                                                                                                 \
         const u32 px_ = readlane_u(ev.pix, kB * (B) + j);                                                             \
-        f[j] = *reinterpret_cast<const float4 *>(slab + (((px_ & 127u) << 10) + lane_base));                          \
+        f[j] = lds_read_b128((px_ << 10) + row_base);                                                                 \
     }
-#define GWBP_FMA8(B)                                                                                                  \
-    _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                    \
+#define GWBP_FMA(B, J0, J1)                                                                                           \
+    _Pragma("unroll") for (int j = J0; j < J1; ++j)                                                                   \
     {                                                                                                                 \
         const float w = readlane_f(ev.w, kB * (B) + j);                                                               \
         acc.x = __builtin_fmaf(w, f[j].x, acc.x);                                                                     \
@@ -222,13 +255,23 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         for (int B = 0; B < 64 / kB; ++B) {
             if ((u32)kB * B >= n)
                 break;
-            GWBP_ISSUE8(B)
-            GWBP_FMA8(B)
+#ifdef GWBP_TAIL4
+            if (n - (u32)kB * B <= 4u) { // short tail: half a batch (a visit averages 34 entries: ~4 % fewer pair steps)
+                GWBP_ISSUE(B, 0, 4)
+                GWBP_FMA(B, 0, 4)
+                break;
+            }
+#endif
+            GWBP_ISSUE(B, 0, kB)
+            GWBP_FMA(B, 0, kB)
         }
-#undef GWBP_ISSUE8
-#undef GWBP_FMA8
+#undef GWBP_ISSUE
+#undef GWBP_FMA
     };
     auto process = [&](const Visit &R, const Pre &x) __attribute__((always_inline)) { // exactly kFlush VMEM operations
+#ifdef GWBP_PROFILE
+        ++n_vis_prof;
+#endif
         const bool resume = phase && R.span;
         acc = resume ? make_float4(x.c[0], x.c[1], x.c[2], x.c[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (!(dbg & 2)) {
@@ -302,10 +345,24 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     }
     // Drain: (1) the last prefetch still targets pA/pB's registers, (2) the carry rows parked in the top pass must be
     // in L2 before any wave of the bottom pass loads them, (3) the slab is about to be overwritten.
+    GWBP_STAMP(ts2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GWBP_STAMP(ts3);
     __syncthreads();
+#ifdef GWBP_PROFILE
+    {
+        GWBP_STAMP(ts4);
+        prof_acc[0] += ts1 - ts0, prof_acc[1] += ts2 - ts1, prof_acc[2] += ts3 - ts2, prof_acc[3] += ts4 - ts3;
+        prof_acc[4] += 1ull, prof_acc[5] += (unsigned long long)n_vis_prof;
+    }
+#endif
     } // phase
     } // item loop
+#ifdef GWBP_PROFILE
+    if (lane == 0)
+        for (int i = 0; i < 6; ++i)
+            atomicAdd(&g_wide_prof[i], prof_acc[i]);
+#endif
     // the last workgroup of the class to leave re-arms the queue (see k_scatter_full)
     if (threadIdx.x == 0) {
         const u32 left = atomicAdd(queue + 1, 1u);
@@ -317,6 +374,16 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
 }
 
 } // namespace
+
+#ifdef GWBP_PROFILE
+extern "C" int gwbp_profile_read_wide(unsigned long long *out8_host)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_wide_prof), sizeof(z)) != hipSuccess)
+        return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wide_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int launch_scatter_wide(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
                         float *F, hipStream_t s)
