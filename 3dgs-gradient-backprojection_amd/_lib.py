@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 EXPORTS = [
     "gwbp_version", "gwbp_last_error_string", "gwbp_workspace_size", "gwbp_project", "gwbp_bin_sort",
     "gwbp_blend_weights", "gwbp_blend_weights_d", "gwbp_accumulate_d", "gwbp_scatter", "gwbp_scatter_upsampled", "gwbp_scatter_bilinear", "gwbp_render", "gwbp_render_pixels", "gwbp_sh_colors",
-    "gwbp_backproject_view", "gwbp_finalize",
+    "gwbp_backproject_view", "gwbp_encode_map", "gwbp_finalize",
     "gwbp_accumulate_stats", "gwbp_read_stats", "gwbp_dump_pairs",
 ]
 
@@ -88,6 +88,7 @@ ARGTYPES = {
     "gwbp_render_pixels": _WSV + [_P, _I32, _P, _P, _P],
     "gwbp_sh_colors": [_I64, _I32, _I32, _P, _P, C.POINTER(C.c_float), _P, _P],
     "gwbp_backproject_view": _WSV + [_P] * 4 + _MAP + [_F, _F, _P, _P, _P],
+    "gwbp_encode_map": [_P, _I64, _I64, _I32, _I32, _I32, _P, _I32, _P, _P],
     "gwbp_finalize": [_I64, _I32, _P, _P, _P, _P],
     "gwbp_accumulate_stats": _WS + [_P, _P],
     "gwbp_read_stats": _WS + [C.POINTER(Stats), _P],

@@ -113,7 +113,8 @@ class ViewPipeline:
     """
 
     def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None,
-                 allow_wide: bool = True, scatter_workgroups: Optional[int] = None, side_priority: int = -1):
+                 allow_wide: bool = True, scatter_workgroups: Optional[int] = None, side_priority: int = -1,
+                 front_priority: Optional[bool] = None):
         self.dev = torch.device(device)
         self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev, tight_binning=True)
                                                   for _ in range(2)]
@@ -128,8 +129,10 @@ class ViewPipeline:
         # then run strictly one after the other and the step is front + scatter (5.06 instead of 4.27 ms/view at C2).
         self.scatter_dim = scatter_dim
         self.allow_wide = bool(allow_wide)
+        self.front_priority = front_priority  # None: raised wave priority for the front exactly when the wide kernel runs
         self.choose_scatter_kernel(None, None)
         self.side = torch.cuda.Stream(device=self.dev, priority=int(side_priority))
+        self.enc_stream = None  # third stream, created by the first encode_ahead()
         self.ev_front = [torch.cuda.Event() for _ in range(2)]
         self.ev_done = [torch.cuda.Event() for _ in range(2)]
         self.accum = torch.zeros(32, dtype=torch.uint8, device=self.dev)
@@ -155,7 +158,7 @@ class ViewPipeline:
         self.wide = wide
         for e in self.eng:
             e.set_narrow_scatter(not wide)
-            e.set_front_priority(wide)
+            e.set_front_priority(wide if self.front_priority is None else bool(self.front_priority))
         return "wide" if wide else "narrow"
 
     def front(self, view, means, quats, scales, opacities, d=None, scale_d=1.0):
@@ -178,11 +181,32 @@ class ViewPipeline:
         self.pending[self.i_front] = (view, d_done)
         self.i_front += 1
 
-    def scatter(self, feats, F, d, scale_f=1.0, scale_d=1.0, t0=None, t1=None, upsample=None):
-        """t0/t1: optional timing events recorded right around the scatter launch (after the cross-stream wait)."""
+    def encode_ahead(self, feats: torch.Tensor, encoder: torch.Tensor):
+        """The compressed variant's per-pixel encoder (backproject_compressed.py:127) for a LATER view on a third stream:
+        an HBM-streaming kernel that overlaps with the latency-bound scatter of the current view and the front stage of
+        the next.  Call it for view v+1 before scatter(v) is enqueued; hand the returned (map, event) to scatter()."""
+        main = torch.cuda.current_stream(self.dev)
+        if self.enc_stream is None:
+            self.enc_stream = torch.cuda.Stream(device=self.dev, priority=-1)
+        ready = torch.cuda.Event()
+        ready.record(main)  # the map was produced on the caller's stream
+        with torch.cuda.stream(self.enc_stream):
+            self.enc_stream.wait_event(ready)
+            out = self.eng[0].encode_map(feats, encoder)
+            done = torch.cuda.Event()
+            done.record(self.enc_stream)
+        feats.record_stream(self.enc_stream)
+        out.record_stream(main)
+        return out, done
+
+    def scatter(self, feats, F, d, scale_f=1.0, scale_d=1.0, t0=None, t1=None, upsample=None, after=None):
+        """t0/t1: optional timing events recorded right around the scatter launch (after the cross-stream waits).
+        after: an event the feature map depends on (encode_ahead)."""
         i = self.i_scatter
         b = i % 2
         main = torch.cuda.current_stream(self.dev)
+        if after is not None:
+            main.wait_event(after)
         main.wait_event(self.ev_front[b])
         e = self.eng[b]
         if t0 is not None:
@@ -253,23 +277,29 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                                                                                 pair_cap=eng.pair_cap)])
                 views = [eng.view(vm_host[v], K_host, width, height) for v in my_views]
                 pipe.front(views[0], means, quats, scales, opacities, d, sd)
+                # with an encoder the feature function runs one view ahead, so that view v+1's map is encoded on a third
+                # stream while view v is scattered (two full-width maps are alive at a time)
+                ahead = pipe.encode_ahead(feature_fn(my_views[0]), encoder) if encoder is not None else None
                 for i, v in enumerate(my_views):
                     if i == 2:  # one host sync per job: views 0 and 1 are counted, pick the scatter kernel for the rest
                         st01 = pipe.stats()
                         pipe.choose_scatter_kernel(st01["n_pairs"], st01["n_headers"])
                     if i + 1 < len(my_views):
                         pipe.front(views[i + 1], means, quats, scales, opacities, d, sd)
-                    feats = feature_fn(v)
                     if encoder is not None:
-                        feats = feats @ encoder
-                    pipe.scatter(feats, F, d, sf, sd, upsample=upsample)
+                        feats, after = ahead
+                        if i + 1 < len(my_views):
+                            ahead = pipe.encode_ahead(feature_fn(my_views[i + 1]), encoder)
+                    else:
+                        feats, after = feature_fn(v), None
+                    pipe.scatter(feats, F, d, sf, sd, upsample=upsample, after=after)
                 stats = pipe.stats()
             else:
                 accum = torch.zeros(32, dtype=torch.uint8, device=dev)
                 for i, v in enumerate(my_views):
                     feats = feature_fn(v)
                     if encoder is not None:
-                        feats = feats @ encoder
+                        feats = eng.encode_map(feats, encoder)
                     view = eng.view(vm_host[v], K_host, width, height)
                     if upsample is None:
                         eng.backproject_view(view, means, quats, scales, opacities, feats, F, d, sf, sd)

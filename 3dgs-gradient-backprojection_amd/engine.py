@@ -303,6 +303,25 @@ class Engine:
                                              C.c_int64(sc), D, C.c_float(scale_f), C.c_float(scale_d), ptr(F),
                                              ptr(d), self._stream())
 
+    def encode_map(self, feats: torch.Tensor, encoder: torch.Tensor) -> torch.Tensor:
+        """feats[H,W,K] @ encoder[K,n] (backproject_compressed.py:127) -> [H,W,n].  The hand-written skinny GEMM
+        (gwbp_encode_map: the map is read once at HBM rate, exact fp32 MFMA) when the shape allows -- n <= 16, K % 16 == 0,
+        channel-contiguous 16-B aligned pixels -- otherwise the library GEMM behind torch.matmul."""
+        if feats.dim() != 3 or encoder.dim() != 2 or feats.shape[2] != encoder.shape[0]:
+            raise GwbpError(f"encode_map: [H,W,K] @ [K,n] expected, got {tuple(feats.shape)} @ {tuple(encoder.shape)}")
+        H, W, K = feats.shape
+        n = encoder.shape[1]
+        sy, sx, sc = feats.stride()
+        ok = (feats.is_cuda and feats.dtype == torch.float32 and encoder.dtype == torch.float32 and n <= 16 and
+              K % 16 == 0 and K <= 2048 and sc == 1 and sy % 4 == 0 and sx % 4 == 0 and feats.data_ptr() % 16 == 0
+              and sy >= 0 and sx >= 0)
+        if not ok:
+            return feats @ encoder
+        enc = encoder.contiguous()
+        out = torch.empty(H, W, n, device=feats.device, dtype=torch.float32)
+        self._call("gwbp_encode_map", ptr(feats), sy, sx, H, W, K, ptr(enc), n, ptr(out), self._stream())
+        return out
+
     def finalize(self, F, d, out=None):
         out = torch.empty_like(F) if out is None else out
         self._call("gwbp_finalize", C.c_int64(F.shape[0]), F.shape[1], ptr(F), ptr(d), ptr(out), self._stream())

@@ -43,6 +43,8 @@ def main():
                     help="scatter kernel for D %% 256 == 0: auto = chosen from the warm-up views' counters")
     ap.add_argument("--pipe-wgs", type=int, default=None, help="persistent scatter workgroups (tuning)")
     ap.add_argument("--side-prio", type=int, default=-1, help="HIP priority of the front stage's stream")
+    ap.add_argument("--front-prio", choices=("auto", "on", "off"), default="auto",
+                    help="raised wave priority for the front-stage kernels (auto: with the 256-channel scatter kernel)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run result check (the `checked` object)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
     ap.add_argument("--exact-binning", action="store_true",
@@ -105,7 +107,8 @@ def main():
     else:
         eng2 = gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap, tight_binning=tight)
         pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng, eng2], scatter_dim=D, allow_wide=allow_wide,
-                                     scatter_workgroups=args.pipe_wgs, side_priority=args.side_prio)
+                                     scatter_workgroups=args.pipe_wgs, side_priority=args.side_prio,
+                                     front_priority=None if args.front_prio == "auto" else args.front_prio == "on")
         accum = pipe.accum
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
@@ -123,11 +126,22 @@ def main():
                 with torch.cuda.stream(pipe.side):
                     ev[k][1].record(pipe.side)
 
+    ahead = {}
+
+    def encode(i):
+        """backproject_compressed.py:127 for view i on the pipeline's third stream (inside the timed region for every
+        timed view: run_views issues it one view ahead of the scatter that consumes it)."""
+        if encoder is not None and not args.serial and i < n_total:
+            ahead[i] = pipe.encode_ahead(pool[i % args.pool], encoder)
+
     def scatter(i):
         k = i - args.warmup
-        feats = pool[i % args.pool]
+        feats, after = pool[i % args.pool], None
         if encoder is not None:
-            feats = feats @ encoder  # backproject_compressed.py:127 happens inside the timed step
+            if args.serial:
+                feats = eng.encode_map(feats, encoder)
+            else:
+                feats, after = ahead.pop(i)
         if args.serial:  # one stream, one workspace: the pre-pipelining schedule
             eng.project(views[i], means, quats, scales, opac)
             eng.bin_sort(views[i])
@@ -140,16 +154,18 @@ def main():
                 ev[k][3].record()
             return
         timed = 0 <= k < args.steps
-        pipe.scatter(feats, F, d, t0=ev[k][2] if timed else None, t1=ev[k][3] if timed else None)
+        pipe.scatter(feats, F, d, t0=ev[k][2] if timed else None, t1=ev[k][3] if timed else None, after=after)
 
     def run_views(lo, hi):
         """Views lo..hi-1 through the two-deep pipeline; every front and every scatter of the range is enqueued here."""
         if lo >= hi:
             return
         front(lo)
+        encode(lo)
         for i in range(lo, hi):
             if i + 1 < hi:
                 front(i + 1)
+                encode(i + 1)
             scatter(i)
 
     run_views(0, args.warmup)

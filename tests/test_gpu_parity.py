@@ -520,3 +520,26 @@ def test_create_feature_field_bilinear_matches_materialised(dev):
     c = gsbp_amd.create_feature_field(*args, feature_fn=lambda v: lows[v], dim=D, upsample="bilinear", pipeline=False)
     assert rel_row_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
     assert rel_row_err(c.cpu().numpy(), b.cpu().numpy()) <= 2e-5
+
+
+@pytest.mark.parametrize("H,W,K,n", [(37, 53, 512, 16), (16, 16, 64, 5), (9, 7, 32, 1), (40, 24, 128, 13)])
+def test_encode_map_matches_matmul(dev, H, W, K, n):
+    """gwbp_encode_map (backproject_compressed.py:127, fp32 MFMA skinny GEMM) against a float64 matmul; dense and
+    pixel-strided maps, pixel counts that are not multiples of the 16-pixel MFMA tile, fewer than 16 outputs."""
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    feats = torch.randn(H, W, K, generator=g)
+    enc = torch.randn(K, n, generator=g) / K ** 0.5
+    eng = gsbp_amd.Engine(16, W, H, device=dev)
+    ref = (feats.double() @ enc.double()).numpy()
+    out = eng.encode_map(feats.to(dev), enc.to(dev))
+    assert tuple(out.shape) == (H, W, n)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()) * K ** 0.5
+    # a view into a wider buffer: pixel stride 2K, row stride with a gap
+    big = torch.zeros(H, W + 3, 2 * K, device=dev)
+    big[:, :W, :K] = feats.to(dev)
+    out2 = eng.encode_map(big[:, :W, :K], enc.to(dev))
+    assert torch.equal(out2, out)
+    # shapes the kernel does not take fall back to the library GEMM with the same result up to rounding
+    out3 = eng.encode_map(feats.to(dev)[:, :, : K - 8], enc.to(dev)[: K - 8])
+    ref3 = (feats[:, :, : K - 8].double() @ enc[: K - 8].double()).numpy()
+    assert np.abs(out3.cpu().numpy() - ref3).max() <= 2e-5

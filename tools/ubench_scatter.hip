@@ -186,6 +186,46 @@ __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ w
                         acc2.y = __builtin_fmaf(e4[j].z, g[2 * j + 1].w, acc2.y);
                     }
                 }
+            } else if (MODE == 10 || MODE == 11) {
+                // mode 5 with the NEXT batch's LDS reads issued before the current batch's FMAs (two batches in flight):
+                // 10 = batches of 4 (8 float4 = 32 VGPRs like mode 5), 11 = batches of 8 (64 VGPRs)
+                constexpr int KB = MODE == 10 ? 4 : 8;
+                constexpr int NBT = 8 / KB; // batches per b-iteration
+                float4 ga[KB], gb[KB];
+#define UB_ISSUE(idx0, g)                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < KB; ++j)                                                                    \
+    {                                                                                                                 \
+        const int p = rl_i(pv, (idx0) + j) & 31;                                                                      \
+        g[j] = *(const float4 *)(slab + ((p << 10) + lane * 16));                                                     \
+    }
+#define UB_FMA(idx0, g)                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < KB; ++j)                                                                    \
+    {                                                                                                                 \
+        const float w = rl_f(wv, (idx0) + j);                                                                         \
+        acc.x = __builtin_fmaf(w, g[j].x, acc.x);                                                                     \
+        acc.y = __builtin_fmaf(w, g[j].y, acc.y);                                                                     \
+        acc2.x = __builtin_fmaf(w, g[j].z, acc2.x);                                                                   \
+        acc2.y = __builtin_fmaf(w, g[j].w, acc2.y);                                                                   \
+    }
+                if (b == 0) {
+                    UB_ISSUE(0, ga)
+                }
+                if (NBT == 2) {
+                    UB_ISSUE(8 * b + 4, gb)
+                    UB_FMA(8 * b, ga)
+                    UB_ISSUE((8 * b + 8) & 63, ga)
+                    UB_FMA(8 * b + 4, gb)
+                } else {
+                    if (b & 1) {
+                        UB_ISSUE((8 * b + 8) & 63, ga)
+                        UB_FMA(8 * b, gb)
+                    } else {
+                        UB_ISSUE((8 * b + 8) & 63, gb)
+                        UB_FMA(8 * b, ga)
+                    }
+                }
+#undef UB_ISSUE
+#undef UB_FMA
             } else if (MODE == 5) {
                 float4 g[8];
 #pragma unroll
@@ -250,6 +290,8 @@ int main()
     run<5>("5 readlane x2 + add + b128 + 2pkfma", iters, w, p, out, 2.0);
     run<6>("6 LDS bcast b64/pair + add+b64+pkfma", iters, w, p, out);
     run<7>("7 LDS bcast b128/2pairs + ...", iters, w, p, out);
+    run<10>("10 mode 5, 2 batches of 4 in flight", iters, w, p, out, 2.0);
+    run<11>("11 mode 5, 2 batches of 8 in flight", iters, w, p, out, 2.0);
     run<8>("8 2 pairs/instr: b64 ent + add + b128 + 2pkfma", iters, w, p, out, 2.0);
     run<9>("9 2 pairs/instr: b128 ent/2 steps + ...", iters, w, p, out, 2.0);
     return 0;
