@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--pool", type=int, default=4, help="feature maps cycled through (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-views", type=int, default=3, help="views of the workload the CPU baseline is timed on")
+    ap.add_argument("--cpu-views", type=int, default=8, help="views of the workload the CPU baseline is timed on")
     ap.add_argument("--scatter", choices=("auto", "wide", "narrow"), default="auto",
                     help="scatter kernel for D %% 256 == 0: auto = chosen from the warm-up views' counters")
     ap.add_argument("--pipe-wgs", type=int, default=None, help="persistent scatter workgroups (tuning)")
@@ -346,7 +346,7 @@ def cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder,
     box's host cores on a bounded sample of the same workload."""
     from oracle import oracle as orc
     import numpy as np
-    cores = os.cpu_count() or 1
+    cores = orc.usable_cores()  # CPUs this container may use (cgroup quota), not os.cpu_count()
     h = [t.cpu().numpy() for t in (means, quats, scales, opac)]
     Fc = np.zeros((cfg.n_gaussians, D), np.float32)
     dc = np.zeros(cfg.n_gaussians, np.float32)
@@ -361,7 +361,8 @@ def cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder,
         pairs += info["n_pairs"]
     return {"value": pairs * D / t, "unit": "Gaussian-pixel-features/s", "cores": cores, "kind": "port",
             "sample": f"{n_views} view(s) of {cfg.name} at full size (N={cfg.n_gaussians}, {cfg.width}x{cfg.height}, "
-                      f"D={D}), oracle/gwbp_oracle.c with OpenMP on all host cores, fp32 accumulators",
+                      f"D={D}), oracle/gwbp_oracle.c with OpenMP on the {cores} CPUs this container may use "
+                      f"(os.cpu_count() = {os.cpu_count()}), fp32 accumulators",
             "seconds": t, "views_per_sec": n_views / t}
 
 

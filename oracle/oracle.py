@@ -31,12 +31,37 @@ def build(force: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
+        os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))  # read when libgomp starts (sort, projection)
         _LIB = C.CDLL(build())
         _LIB.orc_count_isects.restype = C.c_int64
         _LIB.orc_blend_pairs.restype = C.c_int64
         _LIB.orc_exp_neg_export.restype = C.c_float
         _LIB.orc_exp_neg_export.argtypes = [C.c_float]
     return _LIB
+
+
+def usable_cores() -> int:
+    """Threads worth starting: the CPUs this process may run on, capped by the container's CPU quota (cgroup v2
+    cpu.max / v1 cfs quota).  On the GPU boxes os.cpu_count() is 256 but the quota is 16 CPUs: 256 OpenMP threads there
+    run 5-50x SLOWER than 16."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 def _p(a: Optional[np.ndarray]):
@@ -117,7 +142,7 @@ def blend_scatter(proj, bins, opacities, feats: np.ndarray, F: np.ndarray, d: np
     fs = [s // 4 for s in feats.strides]
     alphas = np.zeros((H, W), np.float32) if want_alphas else None
     npairs = C.c_int64(0)
-    nt = nthreads or (os.cpu_count() or 1)
+    nt = nthreads or usable_cores()
     if row_of is not None:
         row_of = np.ascontiguousarray(row_of, dtype=np.int32)
         assert row_of.shape == (op.shape[0],) and int(row_of.max()) < F.shape[0]
