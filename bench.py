@@ -267,7 +267,13 @@ def main():
                          # bytes chip-wide (MI355X_MICROARCH.md, Global float atomics); one flush per (Gaussian, tile)
                          "atomic_added_GBs": n_hdr * (D + 1) * 4.0 / (t_scatter * 1e-3) / 1e9,
                          "atomic_peak_GBs": 1300.0,
-                         "atomic_frac": n_hdr * (D + 1) * 4.0 / (t_scatter * 1e-3) / 1e9 / 1300.0},
+                         "atomic_frac": n_hdr * (D + 1) * 4.0 / (t_scatter * 1e-3) / 1e9 / 1300.0,
+                         # third ceiling, the one the 256-channel kernel's loop actually runs into:
+                         # every (pair, channel) product reads 4 B of the LDS slab; MI355X_MICROARCH.md: ~150 TB/s
+                         # aggregate for ds_read_b64/b128 with every CU streaming
+                         "lds_read_GBs": pairs_view * D * 4.0 / (t_scatter * 1e-3) / 1e9,
+                         "lds_peak_GBs": 150000.0,
+                         "lds_frac": pairs_view * D * 4.0 / (t_scatter * 1e-3) / 1e9 / 150000.0},
         }
         out["checked"] = checked
         if not args.no_cpu_baseline and world == 1:
