@@ -58,6 +58,8 @@ class Image:
     tvec: np.ndarray
     camera_id: int
     name: str
+    xys: Optional[np.ndarray] = None          # [P, 2] float64 2-D observations (images.bin)
+    point3D_ids: Optional[np.ndarray] = None  # [P] int64, -1 = not triangulated
 
     @property
     def t(self):
@@ -72,9 +74,15 @@ class Image:
 
 @dataclass
 class ColmapProject:
-    """The subset of pycolmap_scene_manager.SceneManager the reference touches: .cameras, .images."""
+    """The subset of pycolmap_scene_manager.SceneManager the reference touches: .cameras, .images, and the sparse
+    points its load_checkpoint also loads (utils.py:28-31: load_cameras, load_images, load_points3D)."""
     cameras: Dict[int, Camera] = field(default_factory=dict)
     images: Dict[int, Image] = field(default_factory=dict)
+    points3D: Optional[np.ndarray] = None        # [M, 3] float64
+    point3D_ids: Optional[np.ndarray] = None     # [M] uint64
+    point3D_colors: Optional[np.ndarray] = None  # [M, 3] uint8
+    point3D_errors: Optional[np.ndarray] = None  # [M] float64
+    point3D_id_to_images: Dict[int, np.ndarray] = field(default_factory=dict)  # id -> [T, 2] (image_id, point2D_idx)
 
 
 def read_colmap_model(sparse_dir: str) -> ColmapProject:
@@ -103,8 +111,32 @@ def read_colmap_model(sparse_dir: str) -> ColmapProject:
                     break
                 name += c
             (npts,) = struct.unpack("<Q", f.read(8))
-            f.seek(24 * npts, os.SEEK_CUR)  # (x, y, point3D_id) per 2-D observation: not needed here
-            proj.images[iid] = Image(iid, q, t, cid, name.decode("utf-8"))
+            obs = np.frombuffer(f.read(24 * npts), dtype=np.dtype([("x", "<f8"), ("y", "<f8"), ("id", "<i8")]))
+            proj.images[iid] = Image(iid, q, t, cid, name.decode("utf-8"),
+                                     np.stack([obs["x"], obs["y"]], axis=1) if npts else np.zeros((0, 2)),
+                                     obs["id"].copy())
+    p3 = os.path.join(sparse_dir, "points3D.bin")
+    if os.path.exists(p3):  # utils.py:31 load_points3D (the back-projection itself never reads them)
+        read_points3D(p3, proj)
+    return proj
+
+
+def read_points3D(path: str, proj: Optional[ColmapProject] = None) -> ColmapProject:
+    """points3D.bin of a COLMAP sparse model: per point id (u64), xyz (3 x f64), rgb (3 x u8), reprojection error
+    (f64) and its track, (image_id i32, point2D_idx i32) per observation."""
+    proj = proj if proj is not None else ColmapProject()
+    ids, xyz, rgb, err = [], [], [], []
+    with open(path, "rb") as f:
+        (n,) = struct.unpack("<Q", f.read(8))
+        for _ in range(n):
+            pid, x, y, z, r, g, b, e, tl = struct.unpack("<Q3d3BdQ", f.read(8 + 24 + 3 + 8 + 8))
+            track = np.frombuffer(f.read(8 * tl), dtype="<i4").reshape(tl, 2)
+            ids.append(pid), xyz.append((x, y, z)), rgb.append((r, g, b)), err.append(e)
+            proj.point3D_id_to_images[int(pid)] = track.copy()
+    proj.point3D_ids = np.asarray(ids, dtype=np.uint64)
+    proj.points3D = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+    proj.point3D_colors = np.asarray(rgb, dtype=np.uint8).reshape(-1, 3)
+    proj.point3D_errors = np.asarray(err, dtype=np.float64)
     return proj
 
 

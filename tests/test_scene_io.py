@@ -80,3 +80,34 @@ def test_ply_reader(tmp_path):
     np.testing.assert_array_equal(s["means"].numpy(), data[:, :3])
     np.testing.assert_array_equal(s["features_rest"].numpy().reshape(n, 45), data[:, 9:54])  # utils.py:79-81 reshape
     np.testing.assert_array_equal(s["opacity"].numpy(), data[:, 54])
+
+
+def test_committed_colmap_model_and_ply_fixture():
+    """Known-answer test on the committed bytes of tests/golden/colmap_sparse (written by make_scene_fixtures.py straight
+    from COLMAP's binary-model format: SIMPLE_RADIAL camera, images out of name order with 2-D observations,
+    points3D.bin with tracks; a .ply in the 3DGS property order incl. normals): utils.load_checkpoint's behaviour
+    (utils.py:20-109) and get_viewmat_from_colmap_image (utils.py:215-219)."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "colmap_sparse")
+    s = sio.load_checkpoint(os.path.join(root, "point_cloud.ply"), root, format="ply", data_factor=2)
+    proj = s["colmap_project"]
+    cam = proj.cameras[7]
+    assert (cam.model, cam.width, cam.height) == ("SIMPLE_RADIAL", 1296, 840)
+    assert (cam.fx, cam.fy, cam.cx, cam.cy) == (1040.5, 1040.5, 648.0, 420.0)  # single focal length shared by x and y
+    assert torch.equal(s["camera_matrix"], torch.tensor([[520.25, 0.0, 324.0], [0.0, 520.25, 210.0], [0.0, 0.0, 1.0]]))
+    assert int(s["camera_matrix"][0, 2] * 2) == 648 and int(s["camera_matrix"][1, 2] * 2) == 420  # backproject.py:85-86
+    assert [im.name for im in sorted(proj.images.values(), key=lambda x: x.name)] == ["frame_00001.JPG", "frame_00002.JPG"]
+    vms = sio.sorted_viewmats(proj)
+    assert torch.equal(vms[0], torch.tensor([[1.0, 0, 0, 0], [0, 1.0, 0, 0], [0, 0, 1.0, 4.0], [0, 0, 0, 1.0]]))
+    # q = (w, x, y, z) = (.5, .5, -.5, .5): R = [[0, -1, 0], [0, 0, -1], [1, 0, 0]]
+    assert torch.allclose(vms[1], torch.tensor([[0.0, -1, 0, 0.25], [0, 0, -1.0, -1.5], [1.0, 0, 0, 3.0], [0, 0, 0, 1.0]]))
+    im1 = proj.images[1]
+    assert im1.xys.shape == (3, 2) and im1.point3D_ids.tolist() == [11, 12, -1] and im1.xys[0].tolist() == [648.0, 420.0]
+    assert proj.point3D_ids.tolist() == [11, 12] and proj.points3D[1].tolist() == [1.5, -2.0, 0.125]
+    assert proj.point3D_colors[0].tolist() == [255, 128, 0] and proj.point3D_errors.tolist() == [0.75, 1.25]
+    assert proj.point3D_id_to_images[11].tolist() == [[1, 0], [2, 0]]
+    # .ply: property j of vertex i holds i * 100 + j; f_rest_* reshaped to (-1, 15, 3) as utils.py:79-81 writes it
+    assert s["means"].tolist() == [[0.0, 1.0, 2.0], [100.0, 101.0, 102.0], [200.0, 201.0, 202.0]]
+    assert s["features_dc"][1, 0].tolist() == [106.0, 107.0, 108.0]
+    assert s["features_rest"][2, 0].tolist() == [209.0, 210.0, 211.0] and s["features_rest"][2, 14, 2].item() == 253.0
+    assert s["opacity"].tolist() == [54.0, 154.0, 254.0]
+    assert s["scaling"][0].tolist() == [55.0, 56.0, 57.0] and s["rotation"][0].tolist() == [58.0, 59.0, 60.0, 61.0]
