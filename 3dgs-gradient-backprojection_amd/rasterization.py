@@ -35,9 +35,24 @@ def get_engine(device, n: int, width: int, height: int) -> Engine:
     return eng
 
 
+def _front_key(view, tensors):
+    """Identity of a front-stage result: the view parameters and the Gaussian tensors (storage + in-place version)."""
+    return (bytes(view), tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors))
+
+
 def _run_front(eng: Engine, view, means, quats, scales, opacities, want_alphas, want_meta, want_store=True):
     """project -> sort (-> blend) with auto-grow of the capacities (one host sync per call: this is the
-    API-compatible path; the fused driver in backproject.py amortises the check)."""
+    API-compatible path; the fused driver in backproject.py amortises the check).
+
+    The reference rasterises every view TWICE with the same Gaussians -- zeros [N,512] for the features, zeros [N,3] for the
+    denominators (backproject.py:115-125,133-143): the second call finds the first one's projection, sorted lists and
+    weight store in the workspace (same view bytes, same tensor storages and versions) and skips the whole front."""
+    key = _front_key(view, (means, quats, scales, opacities))
+    c = getattr(eng, "front_cache", None)
+    if (c is not None and c["key"] == key and (c["store"] or not want_store) and (c["meta"] or not want_meta)
+            and (c["alphas"] is not None or not want_alphas) and (c["halves"] or not eng._wide_requested())):
+        return c["proj"], c["bins"], (c["alphas"].clone() if want_alphas else None), c["stats"]
+    eng.front_cache = None
     while True:
         proj = eng.project(view, means, quats, scales, opacities, want_outputs=want_meta)
         bins = eng.bin_sort(view, want_outputs=want_meta)
@@ -45,6 +60,8 @@ def _run_front(eng: Engine, view, means, quats, scales, opacities, want_alphas, 
         st = eng.stats()
         if not st["overflow"]:
             eng.generation += 1
+            eng.front_cache = dict(key=key, proj=proj, bins=bins, alphas=alphas, stats=st, store=want_store,
+                                   meta=want_meta, halves=want_store and eng._halves)
             return proj, bins, alphas, st
         eng.grow(st)
 
@@ -64,6 +81,11 @@ class _Rasterize(torch.autograd.Function):
                                             want_store=need_store)
         if D <= 4:  # RGB / RGB+D / depth: pixel-parallel rasteriser straight from the sorted tile lists
             out, alphas = eng.render_pixels(view, colors.detach())
+        elif colors.requires_grad and not bool(colors.detach().any()):
+            # the reference's harvesting pattern: an all-zero differentiable colour table whose render is only there to be
+            # back-propagated through (backproject.py:67-72,115-129) -- the render of zeros is zeros (0.4 ms to find out
+            # instead of a 5.6 ms wide render at C2)
+            out = torch.zeros(view.height, view.width, D, device=dev, dtype=torch.float32)
         else:
             out = eng.render(view, colors.detach())
         ctx.has_store = need_store
@@ -86,6 +108,7 @@ class _Rasterize(torch.autograd.Function):
             # the workspace was reused by another call since forward: rebuild this view's weight store
             eng = get_engine(means.device, means.shape[0], view.width, view.height)
             eng.set_narrow_scatter(ctx.shape[1] % 256 != 0)
+            eng.front_cache = None
             _run_front(eng, view, means, quats, scales, opacities, False, False)
         v_colors = torch.zeros(ctx.shape, device=means.device, dtype=torch.float32)
         eng.scatter(view, g_out, v_colors, None)

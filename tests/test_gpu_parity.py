@@ -150,6 +150,8 @@ def test_reference_loop_through_dropin_shim(orc, dev, D):
     colors_feats = torch.zeros(N, D, device=dev, requires_grad=True)
     colors_feats_0 = torch.zeros(N, 3, device=dev, requires_grad=True)
     feats_all = [syn.make_feature_map(cfg, v, dim=D) for v in range(cfg.n_views)]
+    from gsbp_amd.rasterization import get_engine
+    gen0 = get_engine(dev, N, cfg.width, cfg.height).generation  # (the engine outlives the test: count from here)
     for v in range(cfg.n_views):
         feats = feats_all[v].to(dev)
         out, _, meta = rasterization(d["means"], d["quats"], d["scales"], d["opac"], colors_feats, d["vms"][v][None],
@@ -175,6 +177,14 @@ def test_reference_loop_through_dropin_shim(orc, dev, D):
                                           cfg.height, lambda v: feats_all[v].numpy(), D)
     assert np.abs(gaussian_features.cpu().numpy() - ref).max() <= TOL
     assert meta["means2d"].shape[1] == 2 and meta["gaussian_ids"].dtype == torch.int64
+    # the second rasterization() of a view (zeros [N,3]) found the first one's projection / lists / weight store in the
+    # workspace: one front pass per view, not two
+    assert get_engine(dev, N, cfg.width, cfg.height).generation == gen0 + cfg.n_views
+    # ... and an in-place change of the Gaussians is noticed
+    d["means"].add_(0.0)
+    rasterization(d["means"], d["quats"], d["scales"], d["opac"], colors_feats_0, d["vms"][0][None], d["K"][None],
+                  width=cfg.width, height=cfg.height)
+    assert get_engine(dev, N, cfg.width, cfg.height).generation == gen0 + cfg.n_views + 1
 
 
 def test_fused_driver_matches_oracle_mean_and_encoder(orc, dev):
