@@ -199,9 +199,10 @@ class ViewPipeline:
         out.record_stream(main)
         return out, done
 
-    def scatter(self, feats, F, d, scale_f=1.0, scale_d=1.0, t0=None, t1=None, upsample=None, after=None):
+    def scatter(self, feats, F, d, scale_f=1.0, scale_d=1.0, t0=None, t1=None, upsample=None, after=None, encoder=None):
         """t0/t1: optional timing events recorded right around the scatter launch (after the cross-stream waits).
-        after: an event the feature map depends on (encode_ahead)."""
+        after: an event the feature map depends on (encode_ahead).
+        encoder: scatter feats @ encoder with the encoder fused into the slab staging (Engine.scatter_encoded)."""
         i = self.i_scatter
         b = i % 2
         main = torch.cuda.current_stream(self.dev)
@@ -212,7 +213,10 @@ class ViewPipeline:
         if t0 is not None:
             t0.record(main)
         view, d_done = self.pending.pop(i)
-        e.scatter(view, feats, F, None if d_done else d, scale_f, scale_d, upsample=upsample)
+        if encoder is not None:
+            e.scatter_encoded(view, feats, encoder, F, None if d_done else d, scale_f, scale_d)
+        else:
+            e.scatter(view, feats, F, None if d_done else d, scale_f, scale_d, upsample=upsample)
         if t1 is not None:
             t1.record(main)
         e.accumulate_stats(self.accum)
@@ -228,7 +232,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                          encoder: Optional[torch.Tensor] = None, engine: Optional[Engine] = None,
                          views: Optional[Sequence[int]] = None, view_fn=None, pipeline: bool = True,
                          return_partials: bool = False, verbose: bool = False, upsample: Optional[str] = None,
-                         gather: bool = True, allow_wide: bool = True):
+                         gather: bool = True, allow_wide: bool = True, fuse_encoder: bool = False):
     """Build the [N, dim_out] per-Gaussian feature field.
 
     means/quats/scales/opacities: post-activation Gaussians (backproject.py:55-57), device tensors.
@@ -242,6 +246,10 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     an [H,W,dim] map per view.
     views: explicit list of view indices for this rank (default: interleaved shard over the process group).
     view_fn: injection point for the per-view accumulate (tests drive the sharding/reduction logic on CPU).
+    fuse_encoder: with `encoder`, apply it inside the scatter kernel's slab staging (gwbp_scatter_encoded: the full-width map
+    is read once, no [H,W,dim_out] intermediate) when the map's layout allows; False (default, measured faster in the
+    three-stream pipeline: C5 2.19 vs 2.29 ms/view; the fused kernel wins on one stream, 2.51 vs 2.70) = a separate encode
+    kernel one view ahead on a third stream (gwbp_encode_map).
     pipeline: overlap the front stages of view v+1 with the scatter of view v (ViewPipeline).
     gather: under a process group, all-gather the finalised row blocks so that every rank returns the whole [N, dim_out]
     field; False returns this rank's block only (rows row0 .. of `return_partials`' stats["row0"]).
@@ -279,13 +287,27 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                 pipe.front(views[0], means, quats, scales, opacities, d, sd)
                 # with an encoder the feature function runs one view ahead, so that view v+1's map is encoded on a third
                 # stream while view v is scattered (two full-width maps are alive at a time)
-                ahead = pipe.encode_ahead(feature_fn(my_views[0]), encoder) if encoder is not None else None
+                fused = None  # decided on the first map: its layout must suit gwbp_scatter_encoded
+                ahead = None
+                if encoder is not None:
+                    first_map = feature_fn(my_views[0])
+                    fused = fuse_encoder and upsample is None and Engine.can_fuse_encoder(first_map, encoder)
+                    ahead = (first_map, None) if fused else pipe.encode_ahead(first_map, encoder)
                 for i, v in enumerate(my_views):
                     if i == 2:  # one host sync per job: views 0 and 1 are counted, pick the scatter kernel for the rest
                         st01 = pipe.stats()
                         pipe.choose_scatter_kernel(st01["n_pairs"], st01["n_headers"])
                     if i + 1 < len(my_views):
                         pipe.front(views[i + 1], means, quats, scales, opacities, d, sd)
+                    if fused:
+                        # the encoder is applied inside the scatter kernel's slab staging: no [H,W,dim_out] map at all
+                        feats = ahead[0] if i == 0 else feature_fn(v)
+                        if not Engine.can_fuse_encoder(feats, encoder):
+                            feats, fenc = eng.encode_map(feats, encoder), None
+                        else:
+                            fenc = encoder
+                        pipe.scatter(feats, F, d, sf, sd, encoder=fenc)
+                        continue
                     if encoder is not None:
                         feats, after = ahead
                         if i + 1 < len(my_views):

@@ -348,6 +348,17 @@ int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
     return scatter_impl(caps, workspace, workspace_bytes, view_host, M, D, scale_f, scale_d, F, d, stream);
 }
 
+int gwbp_scatter_encoded(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                         const float *feats, int64_t fs_y, int64_t fs_x, int32_t K, const float *encoder, int32_t D,
+                         float scale_f, float scale_d, float *F, float *d, void *stream)
+{
+    if (!encoder)
+        return set_error(GWBP_EINVAL, "gwbp_scatter_encoded needs the encoder");
+    FeatMap M{feats, fs_y, fs_x, 1, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    M.enc = encoder, M.enc_k = K;
+    return scatter_impl(caps, workspace, workspace_bytes, view_host, M, D, scale_f, scale_d, F, d, stream);
+}
+
 int gwbp_scatter_upsampled(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
                            const gwbp_view *view_host, const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c,
                            int32_t D, const int32_t *ymap, const int32_t *xmap, float scale_f, float scale_d, float *F,

@@ -161,6 +161,10 @@ struct FeatMap {
     const int32_t *ymap, *xmap;
     const float *ly, *lx;
     int32_t lr_h, lr_w;
+    // gwbp_scatter_encoded (small-D kernel only): the map has enc_k channels per pixel and is multiplied by
+    // enc[enc_k, D] while the tile's slab is staged (backproject_compressed.py:127 without the [H,W,D] intermediate)
+    const float *enc = nullptr;
+    int32_t enc_k = 0;
     __host__ __device__ __forceinline__ int64_t pixel(int iy, int ix) const
     {
         const int64_t yy = ymap ? ymap[iy] : iy, xx = xmap ? xmap[ix] : ix;

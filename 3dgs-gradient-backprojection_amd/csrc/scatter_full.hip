@@ -109,7 +109,11 @@ __device__ __forceinline__ float packed_small_vec(const char *slab, u32 row_byte
 // SMALL = false: D % 128 == 0, 128-channel chunks, lanes = channel pairs (ds_read_b64 + v_pk_fma_f32).
 // SMALL = true : D <= 64 (C1 D = 32, C5 D = 16, the drop-in's 3-channel denominator pass), one chunk, lane l = channel l
 //                (ds_read_b32 + v_fmac), any feature-map strides, slab pitch = D rounded up to 4 floats.
-template <bool SMALL, int VEC> // VEC (slab staging): 1 = 16-B loads, 2 = 16-B loads + bilinear blend, 0 = element-wise
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kEncN = 16; // output channels of one MFMA tile of the fused encoder (D <= 16)
+
+template <bool SMALL, int VEC> // VEC (slab staging): 1 = 16-B loads, 2 = 16-B loads + bilinear blend, 0 = element-wise,
+                               // 3 (SMALL only) = the 512 -> 16 encoder fused in: slab = pixels @ encoder on the MFMA units
 __global__ __launch_bounds__(kThreads) void k_scatter_full(
     ViewDev V, int n_chunks, const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
     const Header *__restrict__ headers, const WPair *__restrict__ wpool, FeatMap M, int pitch_rt, int D,
@@ -138,6 +142,15 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
     const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0)
         s_item[0] = atomicAdd(queue, 1u);
+    // VEC == 3: the encoder lives in LDS behind the slab for the whole (persistent) kernel, re-ordered so that MFMA step
+    // (j, i) reads one conflict-free 256-B row: s_enc[((j * 4 + i) * 4 + q) * 16 + n] = enc[16 j + 4 q + i][n]
+    float *s_enc = lds + kTilePix * pitch + 4;
+    if constexpr (SMALL && VEC == 3) {
+        for (int idx = threadIdx.x; idx < M.enc_k * kEncN; idx += kThreads) {
+            const int n = idx & 15, q = (idx >> 4) & 3, i = (idx >> 6) & 3, j = idx >> 8;
+            s_enc[idx] = n < D ? M.enc[(int64_t)(16 * j + 4 * q + i) * D + n] : 0.f;
+        }
+    }
     __syncthreads();
     for (u32 k = 0;; ++k) {
     const u32 item = uniform(s_item[k & 1u]); // wave-uniform by construction: keep every derived address scalar
@@ -155,7 +168,45 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
     if (threadIdx.x == 0)
         nxt = atomicAdd(queue, 1u); // claim the next item; the value is only needed after the slab is staged
     if (!(dbg & 4) && nh != 0) {
-        if constexpr (SMALL) { // 256 px x pitch floats, element-wise (any strides, zero past D or past the image)
+        if constexpr (SMALL && VEC == 3) {
+            // Fused encoder (backproject_compressed.py:127): wave w stages tile row w -- 16 pixels x enc_k channels read
+            // straight from the full-width map (the only HBM stream of this kernel: 512 KB per tile at enc_k = 512),
+            // times the encoder on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, a k-ordered fmaf chain), 16 x 16
+            // results into the slab.  Lane (m = lane % 16, q = lane / 16) loads the float4 of pixel m at channels
+            // 16 j + 4 q .. + 3; its component i feeds MFMA step (j, i), whose k slot q is channel 16 j + 4 q + i.
+            const int wv = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
+            const int ix = min(tx * kTile + m, V.W - 1), iy = min(ty * kTile + wv, V.H - 1); // edge pixels: never read back
+            const float4 *src = reinterpret_cast<const float4 *>(feats + M.pixel(iy, ix)) + q;
+            const int nb = M.enc_k >> 4;
+            constexpr int kPre = 4; // float4 per lane in flight: 4 KB per wave, 128 KB per CU at two workgroups (64-VGPR budget)
+            float4 a[kPre];
+#pragma unroll
+            for (int u = 0; u < kPre; ++u)
+                a[u] = src[4 * min(u, nb - 1)];
+            f32x4_t acc4 = {0.f, 0.f, 0.f, 0.f};
+            for (int j0 = 0; j0 < nb; j0 += kPre) {
+#pragma unroll
+                for (int u = 0; u < kPre; ++u) {
+                    const int j = j0 + u;
+                    if (j >= nb)
+                        break;
+                    const float4 av = a[u];
+                    if (j + kPre < nb)
+                        a[u] = src[4 * (j + kPre)];
+                    const float *b = s_enc + j * 256 + lane;
+                    acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b[0], acc4, 0, 0, 0);
+                    acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b[64], acc4, 0, 0, 0);
+                    acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b[128], acc4, 0, 0, 0);
+                    acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b[192], acc4, 0, 0, 0);
+                }
+            }
+            // C layout: lane holds output channel n = lane % 16 of pixels 4 * (lane / 16) + r of the wave's row
+            if (m < pitch) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    lds[(wv * kTile + 4 * q + r) * pitch + m] = acc4[r];
+            }
+        } else if constexpr (SMALL) { // 256 px x pitch floats, element-wise (any strides, zero past D or past the image)
             const int total = kTilePix * pitch;
             for (int idx = threadIdx.x; idx < total; idx += kThreads) {
                 const int p = idx / pitch, c = idx - p * pitch;
@@ -471,13 +522,22 @@ int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const Fe
     const int vec_ok = aligned ? (M.bilinear() ? 2 : 1) : 0; // 1: 16-B staging, 2: 16-B bilinear staging, 0: element-wise
     const int n_chunks = small ? 1 : D / kChunk;
     const int pitch = small ? ((D + 3) & ~3) : kChunk;
-    const size_t lds_bytes = (size_t)kTilePix * pitch * sizeof(float) + 16; // slab + work counter + two item slots
+    const bool enc = M.enc != nullptr;
+    if (enc && (!small || D > kEncN || M.enc_k < 16 || (M.enc_k & 15) || M.enc_k > 1024 || !aligned || M.bilinear() || M.ymap))
+        return set_error(GWBP_EINVAL, "fused encoder needs D <= 16, K %% 16 == 0, K <= 1024 and a plain channel-contiguous map");
+    // slab + work counter + two item slots (+ the encoder table for the fused-encoder staging)
+    const size_t lds_bytes = (size_t)kTilePix * pitch * sizeof(float) + 16 + (enc ? (size_t)M.enc_k * kEncN * sizeof(float) : 0);
     const void *fns[4] = {reinterpret_cast<const void *>(k_scatter_full<false, 0>),
                           reinterpret_cast<const void *>(k_scatter_full<false, 1>),
                           reinterpret_cast<const void *>(k_scatter_full<false, 2>),
                           reinterpret_cast<const void *>(k_scatter_full<true, 0>)};
     for (int i = 0; i < 4; ++i) {
         const int rc = ensure_dynamic_lds(fns[i], i < 3 ? (int)kLdsBytes : 65536 + 16, 1 + i);
+        if (rc)
+            return rc;
+    }
+    if (enc) {
+        const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(k_scatter_full<true, 3>), 16384 + 16 + 1024 * kEncN * 4, 8);
         if (rc)
             return rc;
     }
@@ -496,7 +556,9 @@ int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const Fe
 #define GWBP_LAUNCH(S, Vc)                                                                                            \
     hipLaunchKernelGGL((k_scatter_full<S, Vc>), dim3(grid), dim3(kThreads), lds_bytes, s, V, n_chunks, W.tile_offsets,  \
                        W.hdr_count, W.headers, W.wpool, M, pitch, D, scale_f, scale_d, F, d, queues, dbg)
-    if (small)
+    if (enc)
+        GWBP_LAUNCH(true, 3);
+    else if (small)
         GWBP_LAUNCH(true, 0);
     else if (vec_ok == 1)
         GWBP_LAUNCH(false, 1);

@@ -236,6 +236,32 @@ class Engine:
                                               C.c_int64(sc), D, ptr(ymap), ptr(xmap), C.c_float(scale_f),
                                               C.c_float(scale_d), ptr(F), ptr(d), self._stream())
 
+    @staticmethod
+    def can_fuse_encoder(feats: torch.Tensor, encoder: torch.Tensor) -> bool:
+        """Shapes gwbp_scatter_encoded takes: [H,W,K] float32 with channel-contiguous 16-B aligned pixels, K % 16 == 0,
+        K <= 1024, at most 16 outputs."""
+        if feats.dim() != 3 or encoder.dim() != 2 or feats.shape[2] != encoder.shape[0]:
+            return False
+        sy, sx, sc = feats.stride()
+        K, n = encoder.shape
+        return (feats.is_cuda and feats.dtype == torch.float32 and encoder.dtype == torch.float32 and n <= 16
+                and K % 16 == 0 and 16 <= K <= 1024 and sc == 1 and sy % 4 == 0 and sx % 4 == 0 and sy >= 0 and sx >= 0
+                and feats.data_ptr() % 16 == 0)
+
+    def scatter_encoded(self, view, feats, encoder, F, d, scale_f=1.0, scale_d=1.0):
+        """scatter(view, feats @ encoder, ...) of the compressed variant (backproject_compressed.py:127-165) in ONE kernel:
+        the [H,W,K] map is read once, tile by tile, and multiplied by the encoder while the slabs are staged."""
+        if not self.can_fuse_encoder(feats, encoder):
+            raise GwbpError("scatter_encoded: [H,W,K] float32 channel-contiguous map, K % 16 == 0, K <= 1024, <= 16 outputs")
+        if feats.shape[0] != view.height or feats.shape[1] != view.width:
+            raise GwbpError(f"feature map must be [{view.height},{view.width},K], got {tuple(feats.shape)}")
+        sy, sx, _ = feats.stride()
+        K, n = encoder.shape
+        self._check_acc(F, d, n)
+        enc = encoder.contiguous()
+        self._call("gwbp_scatter_encoded", *self._args(), C.byref(view), ptr(feats), sy, sx, K, ptr(enc), n,
+                   C.c_float(scale_f), C.c_float(scale_d), ptr(F), ptr(d), self._stream())
+
     def bilinear_maps(self, h: int, w: int, H: int, W: int):
         """device maps of F.interpolate(mode="bilinear", align_corners=False): (y0[H], ly[H], x0[W], lx[W]); cached."""
         key = ("bilinear", h, w, H, W)

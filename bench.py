@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--side-prio", type=int, default=-1, help="HIP priority of the front stage's stream")
     ap.add_argument("--front-prio", choices=("auto", "on", "off"), default="auto",
                     help="raised wave priority for the front-stage kernels (auto: with the 256-channel scatter kernel)")
+    ap.add_argument("--encoder", choices=("fused", "ahead"), default="ahead",
+                    help="C5: encoder inside the scatter kernel's slab staging, or a separate kernel one view ahead")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run result check (the `checked` object)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
     ap.add_argument("--exact-binning", action="store_true",
@@ -131,14 +133,16 @@ def main():
     def encode(i):
         """backproject_compressed.py:127 for view i on the pipeline's third stream (inside the timed region for every
         timed view: run_views issues it one view ahead of the scatter that consumes it)."""
-        if encoder is not None and not args.serial and i < n_total:
+        if encoder is not None and not args.serial and i < n_total and args.encoder == "ahead":
             ahead[i] = pipe.encode_ahead(pool[i % args.pool], encoder)
 
     def scatter(i):
         k = i - args.warmup
-        feats, after = pool[i % args.pool], None
+        feats, after, fenc = pool[i % args.pool], None, None
         if encoder is not None:
-            if args.serial:
+            if args.encoder == "fused":
+                fenc = encoder
+            elif args.serial:
                 feats = eng.encode_map(feats, encoder)
             else:
                 feats, after = ahead.pop(i)
@@ -148,13 +152,17 @@ def main():
             eng.blend_weights(views[i])
             if 0 <= k < args.steps:
                 ev[k][2].record()
-            eng.scatter(views[i], feats, F, d)
+            if fenc is not None:
+                eng.scatter_encoded(views[i], feats, fenc, F, d)
+            else:
+                eng.scatter(views[i], feats, F, d)
             eng.accumulate_stats(accum)
             if 0 <= k < args.steps:
                 ev[k][3].record()
             return
         timed = 0 <= k < args.steps
-        pipe.scatter(feats, F, d, t0=ev[k][2] if timed else None, t1=ev[k][3] if timed else None, after=after)
+        pipe.scatter(feats, F, d, t0=ev[k][2] if timed else None, t1=ev[k][3] if timed else None, after=after,
+                     encoder=fenc)
 
     def run_views(lo, hi):
         """Views lo..hi-1 through the two-deep pipeline; every front and every scatter of the range is enqueued here."""

@@ -142,6 +142,14 @@ int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
                  const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c, int32_t D, float scale_f,
                  float scale_d, float *F, float *d, void *stream);
 
+/* The compressed variant in one kernel (backproject_compressed.py:127-165): gwbp_scatter of feats[H,W,K] @ encoder[K,D]
+ * (D <= 16, K % 16 == 0, K <= 1024, channel-contiguous 16-B aligned pixels: feats[y*fs_y + x*fs_x + k]) without ever
+ * writing the [H,W,D] map: every tile's pixels are read once, full width, and multiplied by the encoder (resident in LDS)
+ * on the matrix cores while the tile's slab is staged (exact fp32: v_mfma_f32_16x16x4_f32). */
+int gwbp_scatter_encoded(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                         const float *feats, int64_t fs_y, int64_t fs_x, int32_t K, const float *encoder, int32_t D,
+                         float scale_f, float scale_d, float *F, float *d, void *stream);
+
 /* gwbp_scatter over a LOW-RESOLUTION feature map that the reference would first upsample with
  * F.interpolate(mode="nearest") (dino variant, backproject.py:244-248): pixel (y, x) of the view reads
  * feats[ymap[y]*fs_y + xmap[x]*fs_x + c*fs_c].  ymap[view.height], xmap[view.width]: int32 device arrays (the host

@@ -235,6 +235,14 @@ def test_c5_full_size_encoder_path_against_oracle(dev, orc):
     out, F, d, st = gsbp_amd.create_feature_field(*g, vms.to(dev), K.to(dev), cfg.width, cfg.height, lambda v: maps[v],
                                                   cfg.feat_dim, encoder=enc.to(dev), return_partials=True)
     assert st["overflow"] == 0 and tuple(F.shape) == (cfg.n_gaussians, cfg.encoder_dim)
+    # the same job with the encoder fused into the scatter kernel's slab staging (gwbp_scatter_encoded)
+    _, F2, d2, st2 = gsbp_amd.create_feature_field(*g, vms.to(dev), K.to(dev), cfg.width, cfg.height, lambda v: maps[v],
+                                                   cfg.feat_dim, encoder=enc.to(dev), return_partials=True,
+                                                   fuse_encoder=True)
+    assert st2["overflow"] == 0 and st2["n_pairs"] == st["n_pairs"]
+    assert float((F2 - F).norm(dim=1).max()) <= 2e-5 * float(F.norm(dim=1).max())
+    assert float((d2 - d).abs().max()) <= 2e-5 * float(d.max())
+    del F2, d2
     Fr, dr, pairs = _oracle_views(orc, cfg, [t.numpy() for t in g_cpu], vms, K,
                                   [lambda v=v: (maps[v].cpu() @ enc).numpy() for v in range(V)], cfg.encoder_dim)
     assert st["n_pairs"] == pairs

@@ -553,3 +553,41 @@ def test_encode_map_matches_matmul(dev, H, W, K, n):
     out3 = eng.encode_map(feats.to(dev)[:, :, : K - 8], enc.to(dev)[: K - 8])
     ref3 = (feats[:, :, : K - 8].double() @ enc[: K - 8].double()).numpy()
     assert np.abs(out3.cpu().numpy() - ref3).max() <= 2e-5
+
+
+@pytest.mark.parametrize("K,n", [(512, 16), (64, 5), (32, 16)])
+def test_scatter_encoded_matches_scatter_of_encoded_map(orc, dev, K, n):
+    """gwbp_scatter_encoded (the encoder of backproject_compressed.py:127 fused into the slab staging) against the plain
+    scatter of the materialised feats @ encoder, and against the oracle fed the CPU-encoded map; image size not a
+    multiple of the tile (edge tiles), fewer than 16 outputs, a pixel-strided map."""
+    cfg, sc = scene_np("T1")
+    d, h = to_dev(sc, dev), npy(sc)
+    g = torch.Generator().manual_seed(K + n)
+    feats = torch.randn(cfg.height, cfg.width, K, generator=g)
+    enc = torch.randn(K, n, generator=g) / K ** 0.5
+    eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev)
+    view = eng.view(d["vms"][0], d["K"], cfg.width, cfg.height)
+    eng.project(view, d["means"], d["quats"], d["scales"], d["opac"])
+    eng.bin_sort(view)
+    eng.blend_weights(view)
+    big = torch.zeros(cfg.height, cfg.width + 2, K + 16, device=dev)
+    big[:, :cfg.width, :K] = feats.to(dev)
+    res = []
+    for fmap in (feats.to(dev), big[:, :cfg.width, :K]):
+        F = torch.zeros(cfg.n_gaussians, n, device=dev)
+        dd = torch.zeros(cfg.n_gaussians, device=dev)
+        eng.scatter_encoded(view, fmap, enc.to(dev), F, dd)
+        res.append((F, dd))
+    assert torch.equal(res[0][0], res[1][0]) or float((res[0][0] - res[1][0]).abs().max()) <= 1e-5 * float(res[0][0].abs().max())
+    F2 = torch.zeros(cfg.n_gaussians, n, device=dev)
+    d2 = torch.zeros(cfg.n_gaussians, device=dev)
+    eng.scatter(view, eng.encode_map(feats.to(dev), enc.to(dev)), F2, d2)
+    scale = float(F2.norm(dim=1).max())
+    assert float((res[0][0] - F2).norm(dim=1).max()) <= 2e-5 * scale
+    assert float((res[0][1] - d2).abs().max()) <= 2e-5 * float(d2.max())
+    Fr = np.zeros((cfg.n_gaussians, n), np.float64)
+    dr = np.zeros(cfg.n_gaussians, np.float64)
+    orc.backproject_view(h["means"], h["quats"], h["scales"], h["opac"], h["vms"][0], h["K"], cfg.width, cfg.height,
+                         (feats @ enc).numpy(), Fr, dr)
+    assert rel_row_err(res[0][0].cpu().numpy(), Fr) <= TOL
+    assert rel_row_err(res[0][1].cpu().numpy()[:, None], dr[:, None]) <= TOL
