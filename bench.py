@@ -47,6 +47,9 @@ def main():
                     help="raised wave priority for the front-stage kernels (auto: with the 256-channel scatter kernel)")
     ap.add_argument("--encoder", choices=("fused", "ahead"), default="ahead",
                     help="C5: encoder inside the scatter kernel's slab staging, or a separate kernel one view ahead")
+    ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for the one-GPU check)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="every rank uses cuda:0 (checks the N > 1 bookkeeping on a one-GPU box together with --dist-backend gloo)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run result check (the `checked` object)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
     ap.add_argument("--exact-binning", action="store_true",
@@ -68,8 +71,13 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.one_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -210,7 +218,8 @@ def main():
 
     checked = None
     if not args.no_check:
-        checked = check_results(args, gsbp_amd, eng, views, (means, quats, scales, opac), pool, encoder, F_rows, d_sum,
+        # (d itself holds the all-reduced denominators of ALL Gaussians; d_sum is this rank's row block of it)
+        checked = check_results(args, gsbp_amd, eng, views, (means, quats, scales, opac), pool, encoder, F_rows, d,
                                 row0, use_dist, dist, dev)
 
     stats = gsbp_amd.Engine.decode_stats(accum)
