@@ -27,8 +27,9 @@ __device__ __forceinline__ float4 lds_read_b128(unsigned a)
 // MODE 5: like 0 but b128 reads (4 ch/lane, 2 pk_fma) on a 64 KB half slab
 template <int MODE>
 __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ wsrc, const int *__restrict__ psrc,
-                                          float *__restrict__ out)
+                                          float *__restrict__ out, unsigned long long *__restrict__ clk)
 {
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime(), r_start = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 32768; i += 1024)
@@ -226,6 +227,18 @@ __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ w
                 }
 #undef UB_ISSUE
 #undef UB_FMA
+            } else if (MODE == 12 || MODE == 13) {
+                // LDS read rate alone: 8 ds_read_b128 per batch at per-lane fixed addresses (12) or at v_readlane'd pixel
+                // addresses like mode 5 (13); results are only waited for, never used
+                float4 g[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    unsigned a = (unsigned)((((8 * b + j) & 31) << 10) + lane * 16);
+                    if (MODE == 13)
+                        a = (unsigned)(((rl_i(pv, 8 * b + j) & 31) << 10) + lane * 16);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(g[j]) : "v"(a));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             } else if (MODE == 5) {
                 float4 g[8];
 #pragma unroll
@@ -246,25 +259,39 @@ __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ w
         pv = (pv + 1) & 255; // keep the loop from being hoisted
     }
     out[blockIdx.x * 1024 + threadIdx.x] = acc.x + acc.y + acc2.x + acc2.y;
+    if (clk && threadIdx.x == 0) { // in-kernel clock: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime)
+        clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_start;
+        clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r_start;
+    }
 }
 
+static unsigned long long *g_clk = nullptr;
 template <int MODE>
 void run(const char *name, int iters, const float *w, const int *p, float *out, double chunks_per_group = 1.0)
 {
+    if (!g_clk)
+        CHECK(hipMalloc(&g_clk, 512 * sizeof(unsigned long long)));
     CHECK(hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 16384 + 1024));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    k<MODE><<<256, 1024, 131072 + 16384 + 1024>>>(iters, w, p, out);
+    k<MODE><<<256, 1024, 131072 + 16384 + 1024>>>(iters, w, p, out, nullptr);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    k<MODE><<<256, 1024, 131072 + 16384 + 1024>>>(iters, w, p, out);
+    k<MODE><<<256, 1024, 131072 + 16384 + 1024>>>(iters, w, p, out, g_clk);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     // one loop group = one (pair, 128 channels) unit in modes 0-4, 6, 7; two such units in modes 5, 8, 9
     const double pairs_per_cu = (double)iters * 64 * 16 * chunks_per_group; // per CU (16 waves)
+    unsigned long long hc[512];
+    CHECK(hipMemcpy(hc, g_clk, sizeof(hc), hipMemcpyDeviceToHost));
+    double ghz = 0;
+    for (int i = 0; i < 256; ++i)
+        ghz += (double)hc[2 * i] / (double)hc[2 * i + 1] * 0.1;
+    ghz /= 256;
+    printf("[%.2f GHz] ", ghz);
     printf("%-34s %8.3f ms  %6.2f ns/pair/wave  %5.2f pairs/us/CU  -> C2 view (1.35M pair-chunks/CU): %.2f ms\n", name, ms,
            ms * 1e6 / (iters * 64.0), pairs_per_cu / (ms * 1e3), 1.35e6 / (pairs_per_cu / ms));
 }
@@ -292,6 +319,8 @@ int main()
     run<7>("7 LDS bcast b128/2pairs + ...", iters, w, p, out);
     run<10>("10 mode 5, 2 batches of 4 in flight", iters, w, p, out, 2.0);
     run<11>("11 mode 5, 2 batches of 8 in flight", iters, w, p, out, 2.0);
+    run<12>("12 ds_read_b128 only, fixed addresses", iters, w, p, out, 2.0);
+    run<13>("13 ds_read_b128 only, readlane addresses", iters, w, p, out, 2.0);
     run<8>("8 2 pairs/instr: b64 ent + add + b128 + 2pkfma", iters, w, p, out, 2.0);
     run<9>("9 2 pairs/instr: b128 ent/2 steps + ...", iters, w, p, out, 2.0);
     return 0;
