@@ -103,13 +103,17 @@ def finalize_reference(F: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
 
 
 class ViewPipeline:
-    """Two-deep software pipeline over views on two HIP streams and two workspaces.
+    """Software pipeline over views on the caller's stream + side streams, one workspace per view in flight (two by default).
 
     front(v)   = project -> bin/sort -> blend_weights   (small latency-bound kernels + the 20 KB-LDS blend)
     scatter(v) = the weighted scatter-accumulate         (one 139 KB-LDS workgroup per CU: 16 of 32 wave slots)
     front(v+1) runs on a side stream while scatter(v) runs on the caller's stream, so the front kernels fill
-    the wave slots the scatter kernel cannot use.  Events order  front(v) -> scatter(v) -> front(v+2)
-    (workspace reuse).  Nothing synchronises the host.
+    the wave slots the scatter kernel cannot use.  Events order  front(v) -> scatter(v) -> front(v+K)
+    (workspace reuse, K = number of engines).  Nothing synchronises the host.
+
+    With K > 2 engines the fronts of views v+1 .. v+K-1 run concurrently on K-1 side streams (`lookahead` = K - 1): on small
+    scenes the front stage is a chain of ~30 dependent launches that does not fill the chip, and several chains in flight
+    multiply its throughput (pipeline_depth()).
     """
 
     def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None,
@@ -131,10 +135,13 @@ class ViewPipeline:
         self.allow_wide = bool(allow_wide)
         self.front_priority = front_priority  # None: raised wave priority for the front exactly when the wide kernel runs
         self.choose_scatter_kernel(None, None)
-        self.side = torch.cuda.Stream(device=self.dev, priority=int(side_priority))
-        self.enc_stream = None  # third stream, created by the first encode_ahead()
-        self.ev_front = [torch.cuda.Event() for _ in range(2)]
-        self.ev_done = [torch.cuda.Event() for _ in range(2)]
+        K = len(self.eng)
+        self.lookahead = K - 1  # fronts the driver keeps enqueued ahead of the scatter
+        self.sides = [torch.cuda.Stream(device=self.dev, priority=int(side_priority)) for _ in range(max(1, K - 1))]
+        self.side = self.sides[0]
+        self.enc_stream = None  # encoder stream, created by the first encode_ahead()
+        self.ev_front = [torch.cuda.Event() for _ in range(K)]
+        self.ev_done = [torch.cuda.Event() for _ in range(K)]
         self.accum = torch.zeros(32, dtype=torch.uint8, device=self.dev)
         self.i_front = 0    # views whose front stage has been enqueued
         self.i_scatter = 0  # views whose scatter stage has been enqueued
@@ -165,19 +172,21 @@ class ViewPipeline:
         """d (optional): the denominator accumulator.  With the 256-channel scatter kernel chosen, the view's share of d
         is added by the blend itself on the side stream (gwbp_blend_weights_d) and scatter() then leaves d alone: the
         denominators cost nothing on the scatter's stream."""
-        b = self.i_front % 2
+        K = len(self.eng)
+        b = self.i_front % K
+        side = self.sides[self.i_front % len(self.sides)]
         main = torch.cuda.current_stream(self.dev)
-        if self.i_front < 2:
-            self.side.wait_stream(main)  # inputs produced on the caller's stream
+        if self.i_front < K:
+            side.wait_stream(main)  # inputs produced on the caller's stream
         else:
-            self.side.wait_event(self.ev_done[b])  # workspace b is free once scatter(i-2) has finished
-        with torch.cuda.stream(self.side):
+            side.wait_event(self.ev_done[b])  # workspace b is free once scatter(i-K) has finished
+        with torch.cuda.stream(side):
             e = self.eng[b]
             e.project(view, means, quats, scales, opacities)
             e.bin_sort(view)
             d_done = d is not None and self.wide
             e.blend_weights(view, d=d if d_done else None, scale_d=scale_d)
-            self.ev_front[b].record(self.side)
+            self.ev_front[b].record(side)
         self.pending[self.i_front] = (view, d_done)
         self.i_front += 1
 
@@ -204,7 +213,7 @@ class ViewPipeline:
         after: an event the feature map depends on (encode_ahead).
         encoder: scatter feats @ encoder with the encoder fused into the slab staging (Engine.scatter_encoded)."""
         i = self.i_scatter
-        b = i % 2
+        b = i % len(self.eng)
         main = torch.cuda.current_stream(self.dev)
         if after is not None:
             main.wait_event(after)
@@ -225,6 +234,15 @@ class ViewPipeline:
 
     def stats(self):
         return Engine.decode_stats(self.accum)  # synchronises
+
+
+def pipeline_depth(n_gaussians: int, width: int, height: int) -> int:
+    """Workspaces (views in flight) of the ViewPipeline.  2 for large scenes: the scatter kernel is the long stage and one
+    front beside it is all the chip has room for (C2, C4, C5: a third workspace changes nothing).  4 -- three front stages
+    in flight on three side streams -- for small scenes, where a view is ~35 dependent launches of 5-20 us each and the
+    chain, not the chip, is the limit (C1: 0.49 -> 0.19 ms/view; 5 and more lose again: the streams start sharing
+    hardware queues)."""
+    return 4 if (n_gaussians <= 250_000 and width * height <= 1_000_000) else 2
 
 
 def create_feature_field(means, quats, scales, opacities, viewmats, K, width: int, height: int,
@@ -250,7 +268,8 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     is read once, no [H,W,dim_out] intermediate) when the map's layout allows; False (default, measured faster in the
     three-stream pipeline: C5 2.19 vs 2.29 ms/view; the fused kernel wins on one stream, 2.51 vs 2.70) = a separate encode
     kernel one view ahead on a third stream (gwbp_encode_map).
-    pipeline: overlap the front stages of view v+1 with the scatter of view v (ViewPipeline).
+    pipeline: overlap the front stages of the next view(s) with the scatter of view v (ViewPipeline); True = depth chosen by
+    pipeline_depth(N, width, height), an int >= 2 = that many workspaces, False = one stream.
     gather: under a process group, all-gather the finalised row blocks so that every rank returns the whole [N, dim_out]
     field; False returns this rank's block only (rows row0 .. of `return_partials`' stats["row0"]).
     return_partials: also return (F_rows, d, stats): the summed, un-normalised accumulators (this rank's row block of F,
@@ -277,14 +296,15 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
         for attempt in range(6):  # a capacity overflow invalidates the accumulators: grow the workspace, start over
             if pipeline and len(my_views) > 1:
                 # (bilinear maps are staged by the 128-channel kernel only: no wide kernel, no front priority)
+                depth = pipeline_depth(n, width, height) if pipeline is True else max(2, int(pipeline))
                 pipe = ViewPipeline(n, width, height, dev, scatter_dim=None if upsample == "bilinear" else d_out,
                                     allow_wide=allow_wide,
-                                    engines=[eng, Engine(n, width, height, device=dev,
-                                                                                tight_binning=eng.tight_binning,
-                                                                                isect_cap=eng.isect_cap,
-                                                                                pair_cap=eng.pair_cap)])
+                                    engines=[eng] + [Engine(n, width, height, device=dev, tight_binning=eng.tight_binning,
+                                                            isect_cap=eng.isect_cap, pair_cap=eng.pair_cap)
+                                                     for _ in range(depth - 1)])
                 views = [eng.view(vm_host[v], K_host, width, height) for v in my_views]
-                pipe.front(views[0], means, quats, scales, opacities, d, sd)
+                for j in range(min(pipe.lookahead, len(my_views))):
+                    pipe.front(views[j], means, quats, scales, opacities, d, sd)
                 # with an encoder the feature function runs one view ahead, so that view v+1's map is encoded on a third
                 # stream while view v is scattered (two full-width maps are alive at a time)
                 fused = None  # decided on the first map: its layout must suit gwbp_scatter_encoded
@@ -297,8 +317,8 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                     if i == 2:  # one host sync per job: views 0 and 1 are counted, pick the scatter kernel for the rest
                         st01 = pipe.stats()
                         pipe.choose_scatter_kernel(st01["n_pairs"], st01["n_headers"])
-                    if i + 1 < len(my_views):
-                        pipe.front(views[i + 1], means, quats, scales, opacities, d, sd)
+                    if i + pipe.lookahead < len(my_views):
+                        pipe.front(views[i + pipe.lookahead], means, quats, scales, opacities, d, sd)
                     if fused:
                         # the encoder is applied inside the scatter kernel's slab staging: no [H,W,dim_out] map at all
                         feats = ahead[0] if i == 0 else feature_fn(v)

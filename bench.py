@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for the one-GPU check)")
     ap.add_argument("--one-device", action="store_true",
                     help="every rank uses cuda:0 (checks the N > 1 bookkeeping on a one-GPU box together with --dist-backend gloo)")
+    ap.add_argument("--depth", type=int, default=0,
+                    help="workspaces / views in flight of the pipeline (0 = auto: 4 for small scenes, else 2)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run result check (the `checked` object)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
     ap.add_argument("--exact-binning", action="store_true",
@@ -115,8 +117,10 @@ def main():
         eng.set_narrow_scatter(not (D % 256 == 0 and allow_wide))
         pipe, accum = None, torch.zeros(32, dtype=torch.uint8, device=dev)
     else:
-        eng2 = gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap, tight_binning=tight)
-        pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng, eng2], scatter_dim=D, allow_wide=allow_wide,
+        depth = args.depth or gsbp_amd.backproject.pipeline_depth(N, W, H)
+        more = [gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap, tight_binning=tight)
+                for _ in range(depth - 1)]
+        pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng] + more, scatter_dim=D, allow_wide=allow_wide,
                                      scatter_workgroups=args.pipe_wgs, side_priority=args.side_prio,
                                      front_priority=None if args.front_prio == "auto" else args.front_prio == "on")
         accum = pipe.accum
@@ -176,11 +180,14 @@ def main():
         """Views lo..hi-1 through the two-deep pipeline; every front and every scatter of the range is enqueued here."""
         if lo >= hi:
             return
-        front(lo)
+        la = 1 if args.serial else pipe.lookahead
+        for j in range(lo, min(lo + la, hi)):
+            front(j)
         encode(lo)
         for i in range(lo, hi):
+            if i + la < hi:
+                front(i + la)
             if i + 1 < hi:
-                front(i + 1)
                 encode(i + 1)
             scatter(i)
 
@@ -272,7 +279,9 @@ def main():
                        "n_visible_per_view": n_vis, "n_isect_per_view": n_isect, "n_headers_per_view": n_hdr,
                        "binning": "alpha-ellipse bounding box (GWBP_FLAG_TIGHT_BINNING)" if tight else "gsplat 3-sigma square",
                        "overflow": overflow,
-                       "schedule": "serial" if args.serial else "front(v+1) overlapped with scatter(v) on two streams",
+                       "schedule": "serial" if args.serial else
+                       f"front(v+1..v+{pipe.lookahead}) overlapped with scatter(v): {1 + len(pipe.sides)} streams, "
+                       f"{len(pipe.eng)} workspaces",
                        "stage_ms": {"front(project+sort+blend, side stream, overlapped)": t_front,
                                     "scatter": t_scatter}},
             "roofline": {"bound": "hbm", "kernel": scatter_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
