@@ -89,7 +89,7 @@ ARGTYPES = {
     "gwbp_render_pixels": _WSV + [_P, _I32, _P, _P, _P],
     "gwbp_sh_colors": [_I64, _I32, _I32, _P, _P, C.POINTER(C.c_float), _P, _P],
     "gwbp_backproject_view": _WSV + [_P] * 4 + _MAP + [_F, _F, _P, _P, _P],
-    "gwbp_encode_map": [_P, _I64, _I64, _I32, _I32, _I32, _P, _I32, _P, _P],
+    "gwbp_encode_map": [_P, _I64, _I64, _I32, _I32, _I32, _P, _I32, _P, _I32, _P],
     "gwbp_finalize": [_I64, _I32, _P, _P, _P, _P],
     "gwbp_accumulate_stats": _WS + [_P, _P],
     "gwbp_read_stats": _WS + [C.POINTER(Stats), _P],

@@ -201,7 +201,9 @@ class ViewPipeline:
         ready.record(main)  # the map was produced on the caller's stream
         with torch.cuda.stream(self.enc_stream):
             self.enc_stream.wait_event(ready)
-            out = self.eng[0].encode_map(feats, encoder)
+            # one workgroup per CU: streaming harder doubles the memory latency of the front stage and the scatter beside it
+            out = self.eng[0].encode_map(feats, encoder,
+                                         workgroups=torch.cuda.get_device_properties(self.dev).multi_processor_count)
             done = torch.cuda.Event()
             done.record(self.enc_stream)
         feats.record_stream(self.enc_stream)

@@ -455,7 +455,7 @@ int gwbp_backproject_view(const gwbp_caps *caps, void *workspace, size_t workspa
 }
 
 int gwbp_encode_map(const float *feats, int64_t fs_y, int64_t fs_x, int32_t height, int32_t width, int32_t K,
-                    const float *encoder, int32_t n_out, float *out, void *stream)
+                    const float *encoder, int32_t n_out, float *out, int32_t workgroups, void *stream)
 {
     if (!feats || !encoder || !out || height < 1 || width < 1 || K < 16 || K % 16 != 0 || K > 2048 || n_out < 1 ||
         n_out > 16 || fs_y < 0 || fs_x < 0)
@@ -463,7 +463,8 @@ int gwbp_encode_map(const float *feats, int64_t fs_y, int64_t fs_x, int32_t heig
                          height, width, K, n_out);
     if ((reinterpret_cast<uintptr_t>(feats) & 15) || (fs_y & 3) || (fs_x & 3))
         return set_error(GWBP_EINVAL, "encode_map needs channel-contiguous pixels at 16-B aligned addresses");
-    return launch_encode_map(feats, fs_y, fs_x, height, width, K, encoder, n_out, out, static_cast<hipStream_t>(stream));
+    return launch_encode_map(feats, fs_y, fs_x, height, width, K, encoder, n_out, out, workgroups < 0 ? 0 : workgroups,
+                             static_cast<hipStream_t>(stream));
 }
 
 int gwbp_finalize(int64_t N, int32_t D, const float *F, const float *d, float *out, void *stream)

@@ -198,7 +198,7 @@ int launch_render_px(const Ws &W, const ViewDev &V, const float *colors, int D, 
 int launch_sh_colors(int64_t N, int degree, int K, const float *means, const float *coeffs, const float *campos,
                      float *out, hipStream_t s);
 int launch_encode_map(const float *feats, int64_t fs_y, int64_t fs_x, int H, int W, int K, const float *enc, int n_out,
-                      float *out, hipStream_t s);
+                      float *out, int workgroups, hipStream_t s);
 int launch_finalize(int64_t N, int D, const float *F, const float *d, float *out, hipStream_t s);
 int launch_dump_pairs(const Layout &L, const Ws &W, const ViewDev &V, int64_t cap, int32_t *gid, int32_t *pix,
                       float *w, u64 *n_dev, hipStream_t s);

@@ -329,10 +329,11 @@ class Engine:
                                              C.c_int64(sc), D, C.c_float(scale_f), C.c_float(scale_d), ptr(F),
                                              ptr(d), self._stream())
 
-    def encode_map(self, feats: torch.Tensor, encoder: torch.Tensor) -> torch.Tensor:
+    def encode_map(self, feats: torch.Tensor, encoder: torch.Tensor, workgroups: int = 0) -> torch.Tensor:
         """feats[H,W,K] @ encoder[K,n] (backproject_compressed.py:127) -> [H,W,n].  The hand-written skinny GEMM
         (gwbp_encode_map: the map is read once at HBM rate, exact fp32 MFMA) when the shape allows -- n <= 16, K % 16 == 0,
-        channel-contiguous 16-B aligned pixels -- otherwise the library GEMM behind torch.matmul."""
+        channel-contiguous 16-B aligned pixels -- otherwise the library GEMM behind torch.matmul.  workgroups: 0 = fastest
+        alone; one per CU when the call overlaps latency-bound kernels on other streams (ViewPipeline.encode_ahead)."""
         if feats.dim() != 3 or encoder.dim() != 2 or feats.shape[2] != encoder.shape[0]:
             raise GwbpError(f"encode_map: [H,W,K] @ [K,n] expected, got {tuple(feats.shape)} @ {tuple(encoder.shape)}")
         H, W, K = feats.shape
@@ -345,7 +346,7 @@ class Engine:
             return feats @ encoder
         enc = encoder.contiguous()
         out = torch.empty(H, W, n, device=feats.device, dtype=torch.float32)
-        self._call("gwbp_encode_map", ptr(feats), sy, sx, H, W, K, ptr(enc), n, ptr(out), self._stream())
+        self._call("gwbp_encode_map", ptr(feats), sy, sx, H, W, K, ptr(enc), n, ptr(out), int(workgroups), self._stream())
         return out
 
     def finalize(self, F, d, out=None):

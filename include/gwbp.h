@@ -196,9 +196,10 @@ int gwbp_backproject_view(const gwbp_caps *caps, void *workspace, size_t workspa
 
 /* backproject_compressed.py:127: out[y, x, :] = feats[y, x, :] @ encoder, encoder [K, n_out] row-major, n_out <= 16,
  * K % 16 == 0, feats[y*fs_y + x*fs_x + c] (channel-contiguous pixels, 16-B aligned), out [H, W, n_out] dense.  The map is
- * read once at HBM rate; exact fp32 (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain). */
+ * read once at HBM rate; exact fp32 (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain).  workgroups: 0 = as many as
+ * stream fastest alone (6.0 TB/s); a caller that overlaps the encoder with latency-bound kernels passes one per CU. */
 int gwbp_encode_map(const float *feats, int64_t fs_y, int64_t fs_x, int32_t height, int32_t width, int32_t K,
-                    const float *encoder, int32_t n_out, float *out, void *stream);
+                    const float *encoder, int32_t n_out, float *out, int32_t workgroups, void *stream);
 
 /* backproject.py:63,166-169: out = normalize(F / (1e-12 + d)), NaN -> 0.  out may alias F. */
 int gwbp_finalize(int64_t N, int32_t D, const float *F, const float *d, float *out, void *stream);
