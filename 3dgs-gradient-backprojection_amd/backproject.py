@@ -190,6 +190,8 @@ class ViewPipeline:
         self.pending[self.i_front] = (view, d_done)
         self.i_front += 1
 
+    ENCODER_WORKGROUPS_PER_CU = 1.0  # beside the pipeline (see encode_ahead)
+
     def encode_ahead(self, feats: torch.Tensor, encoder: torch.Tensor):
         """The compressed variant's per-pixel encoder (backproject_compressed.py:127) for a LATER view on a third stream:
         an HBM-streaming kernel that overlaps with the latency-bound scatter of the current view and the front stage of
@@ -202,8 +204,8 @@ class ViewPipeline:
         with torch.cuda.stream(self.enc_stream):
             self.enc_stream.wait_event(ready)
             # one workgroup per CU: streaming harder doubles the memory latency of the front stage and the scatter beside it
-            out = self.eng[0].encode_map(feats, encoder,
-                                         workgroups=torch.cuda.get_device_properties(self.dev).multi_processor_count)
+            n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+            out = self.eng[0].encode_map(feats, encoder, workgroups=max(1, int(self.ENCODER_WORKGROUPS_PER_CU * n_cu)))
             done = torch.cuda.Event()
             done.record(self.enc_stream)
         feats.record_stream(self.enc_stream)

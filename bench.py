@@ -52,6 +52,7 @@ def main():
                     help="every rank uses cuda:0 (checks the N > 1 bookkeeping on a one-GPU box together with --dist-backend gloo)")
     ap.add_argument("--depth", type=int, default=0,
                     help="workspaces / views in flight of the pipeline (0 = auto: 4 for small scenes, else 2)")
+    ap.add_argument("--enc-wgs-per-cu", type=float, default=None, help="C5 tuning: encoder workgroups per CU in the pipeline")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run result check (the `checked` object)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
     ap.add_argument("--exact-binning", action="store_true",
@@ -124,6 +125,8 @@ def main():
                                      scatter_workgroups=args.pipe_wgs, side_priority=args.side_prio,
                                      front_priority=None if args.front_prio == "auto" else args.front_prio == "on")
         accum = pipe.accum
+        if args.enc_wgs_per_cu:
+            pipe.ENCODER_WORKGROUPS_PER_CU = args.enc_wgs_per_cu
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     n_total = args.steps + args.warmup
