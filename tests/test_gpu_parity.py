@@ -75,11 +75,14 @@ def test_blend_weights_bit_exact(name, orc, dev):
     assert np.array_equal(alphas.cpu().numpy().view(np.uint32), ralpha.view(np.uint32))
 
 
-@pytest.mark.parametrize("name,D", [("T0", 8), ("T0", 3), ("T1", 24), ("T1", 130), ("C1", 32), ("T1", 512)])
-def test_scatter_parity(name, D, orc, dev):
+@pytest.mark.parametrize("name,D,wide", [("T0", 8, False), ("T0", 3, False), ("T1", 24, False), ("T1", 130, False),
+                                         ("C1", 32, False), ("T1", 512, False), ("T1", 512, True), ("C1", 256, True)])
+def test_scatter_parity(name, D, wide, orc, dev):
+    """wide: the 256-channel kernel (an Engine starts with the 128-channel one; the drivers switch per job)."""
     cfg, sc = scene_np(name)
     d, h = to_dev(sc, dev), npy(sc)
     eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev)
+    eng.set_narrow_scatter(not wide)
     F = torch.zeros(cfg.n_gaussians, D, device=dev)
     dd = torch.zeros(cfg.n_gaussians, device=dev)
     Fr = np.zeros((cfg.n_gaussians, D), np.float64)
