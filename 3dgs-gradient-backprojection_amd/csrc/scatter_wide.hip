@@ -195,9 +195,14 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     const u32 row_base = (u32)(lane * 16) - (phase ? (u32)(kHalfPix << 10) : 0u);
 
     auto claim = [&]() __attribute__((always_inline)) -> u32 {
+        // one lane, one LDS atomic -- written as asm so that hipcc's atomic optimiser does not wrap the already
+        // single-lane add in its wave-aggregation sequence (v_mbcnt x2, s_bcnt1, compare, second exec mask, add: ~8
+        // instructions per visit).  The counter sits right behind the slab; dynamic LDS starts at address 0.
         u32 h = 0;
-        if (lane == 0)
-            h = atomicAdd(s_next, 1u);
+        if (lane == 0) {
+            const u32 addr = (u32)(kSlabFloats * sizeof(float)), one = 1u;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(h) : "v"(addr), "v"(one) : "memory");
+        }
         return uniform(h);
     };
     auto load_visit = [&](u32 h) __attribute__((always_inline)) -> Visit { // scalar loads; an invalid claim re-reads the last header (never processed)
