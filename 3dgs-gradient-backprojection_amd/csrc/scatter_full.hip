@@ -310,9 +310,14 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
     const bool want_d = (chunk == 0) && (dsum_out != nullptr);
 
     auto claim = [&]() __attribute__((always_inline)) -> u32 {
+        // one lane, one LDS atomic, as asm: hipcc's atomic optimiser otherwise wraps the already single-lane add in its
+        // wave-aggregation sequence (~8 more instructions per record); the counter sits right behind the slab and the
+        // kernel's dynamic LDS starts at address 0
         u32 h = 0;
-        if (lane == 0)
-            h = atomicAdd(s_next, 1u);
+        if (lane == 0) {
+            const u32 addr = (u32)(kTilePix * pitch * (int)sizeof(float)), one = 1u;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(h) : "v"(addr), "v"(one) : "memory");
+        }
         return uniform(h);
     };
     auto load_rec = [&](u32 h) __attribute__((always_inline)) -> Rec { // scalar loads; an invalid claim re-reads the last header (never processed)
