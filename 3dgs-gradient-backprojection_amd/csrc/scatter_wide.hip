@@ -88,9 +88,10 @@ __device__ __forceinline__ void issue_e(EV &dst, const WPair *p)
     asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(*reinterpret_cast<float2 *>(&dst)) : "v"(p) : "memory");
 }
 // sc1: served by L2, never by this CU's L1 (the row was written by another wave of this workgroup one pass earlier)
+template <int OFF> // byte offset as an instruction immediate: the four carry loads of a visit share ONE 64-bit address
 __device__ __forceinline__ void issue_c(float &dst, const float *p)
 {
-    asm volatile("global_load_dword %0, %1, off sc1" : "+v"(dst) : "v"(p) : "memory");
+    asm volatile("global_load_dword %0, %1, off offset:%2 sc1" : "+v"(dst) : "v"(p), "n"(OFF) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_pre(Pre &x)
@@ -223,9 +224,10 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
             issue_e(x.e[j], wpool + (R.off + min((u32)(64 * j + lane), last)));
         // carry dwords of this lane (top pass and non-spanning records: row 0, value ignored)
         const float *cr = carry + (size_t)((phase && R.span) ? R.row : 0u) * kWide + lane;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            issue_c(x.c[q], cr + 64 * q);
+        issue_c<0>(x.c[0], cr);
+        issue_c<256>(x.c[1], cr);
+        issue_c<512>(x.c[2], cr);
+        issue_c<768>(x.c[3], cr);
     };
 
     float4 acc;
@@ -296,16 +298,18 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
             cr[0] = acc.x, cr[64] = acc.y, cr[128] = acc.z, cr[192] = acc.w;
         } else {
             float *Fg = F + (int64_t)R.gid * D + c0 + lane;
+            if (scale_f != 1.0f) // wave-uniform; the .sum() reduction of backproject.py:127 needs no scaling
+                acc.x *= scale_f, acc.y *= scale_f, acc.z *= scale_f, acc.w *= scale_f;
             if (!(dbg & 1)) {
-                atomicAdd(Fg, acc.x * scale_f);
-                atomicAdd(Fg + 64, acc.y * scale_f);
-                atomicAdd(Fg + 128, acc.z * scale_f);
-                atomicAdd(Fg + 192, acc.w * scale_f);
+                atomicAdd(Fg, acc.x);
+                atomicAdd(Fg + 64, acc.y);
+                atomicAdd(Fg + 128, acc.z);
+                atomicAdd(Fg + 192, acc.w);
             } else { // ablation: same VMEM count, no atomics
-                __builtin_nontemporal_store(acc.x * scale_f, Fg);
-                __builtin_nontemporal_store(acc.y * scale_f, Fg + 64);
-                __builtin_nontemporal_store(acc.z * scale_f, Fg + 128);
-                __builtin_nontemporal_store(acc.w * scale_f, Fg + 192);
+                __builtin_nontemporal_store(acc.x, Fg);
+                __builtin_nontemporal_store(acc.y, Fg + 64);
+                __builtin_nontemporal_store(acc.z, Fg + 128);
+                __builtin_nontemporal_store(acc.w, Fg + 192);
             }
         }
     };
