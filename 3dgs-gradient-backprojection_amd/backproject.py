@@ -118,7 +118,7 @@ class ViewPipeline:
 
     def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None,
                  allow_wide: bool = True, scatter_workgroups: Optional[int] = None, side_priority: int = -1,
-                 front_priority: Optional[bool] = None):
+                 front_priority: Optional[bool] = None, fuse_small: bool = True):
         self.dev = torch.device(device)
         self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev, tight_binning=True)
                                                   for _ in range(2)]
@@ -133,6 +133,9 @@ class ViewPipeline:
         # then run strictly one after the other and the step is front + scatter (5.06 instead of 4.27 ms/view at C2).
         self.scatter_dim = scatter_dim
         self.allow_wide = bool(allow_wide)
+        # Narrow maps (D <= 16): the front stage stops after the sort, and blend + scatter run as ONE kernel on the caller's
+        # stream (gwbp_blend_scatter: no weight store, no scatter kernel); the side stream keeps project + sort of view v+1.
+        self.fuse_small = bool(fuse_small) and scatter_dim is not None and scatter_dim <= Engine.FUSED_MAX_DIM
         self.front_priority = front_priority  # None: raised wave priority for the front exactly when the wide kernel runs
         self.choose_scatter_kernel(None, None)
         K = len(self.eng)
@@ -184,13 +187,17 @@ class ViewPipeline:
             e = self.eng[b]
             e.project(view, means, quats, scales, opacities)
             e.bin_sort(view)
-            d_done = d is not None and self.wide
-            e.blend_weights(view, d=d if d_done else None, scale_d=scale_d)
+            d_done = d is not None and self.wide and not self.fuse_small
+            if not self.fuse_small:
+                e.blend_weights(view, d=d if d_done else None, scale_d=scale_d)
             self.ev_front[b].record(side)
-        self.pending[self.i_front] = (view, d_done)
+        self.pending[self.i_front] = (view, d_done, not self.fuse_small)
         self.i_front += 1
 
-    ENCODER_WORKGROUPS_PER_CU = 1.0  # beside the pipeline (see encode_ahead)
+    # Encoder workgroups per CU beside the pipeline (see encode_ahead): None = 1 next to the separate blend and small-D
+    # scatter kernels (both latency-bound: C5 2.19 -> 1.96 ms/view against 4 per CU), 2 next to the fused blend+scatter
+    # kernel, where one per CU makes the encoder itself the long pole (C5: 1.65 ms/view at 1, 1.42 at 2, 1.45 at 3)
+    ENCODER_WORKGROUPS_PER_CU = None
 
     def encode_ahead(self, feats: torch.Tensor, encoder: torch.Tensor):
         """The compressed variant's per-pixel encoder (backproject_compressed.py:127) for a LATER view on a third stream:
@@ -205,7 +212,8 @@ class ViewPipeline:
             self.enc_stream.wait_event(ready)
             # one workgroup per CU: streaming harder doubles the memory latency of the front stage and the scatter beside it
             n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
-            out = self.eng[0].encode_map(feats, encoder, workgroups=max(1, int(self.ENCODER_WORKGROUPS_PER_CU * n_cu)))
+            per_cu = self.ENCODER_WORKGROUPS_PER_CU or (2.0 if self.fuse_small else 1.0)
+            out = self.eng[0].encode_map(feats, encoder, workgroups=max(1, int(per_cu * n_cu)))
             done = torch.cuda.Event()
             done.record(self.enc_stream)
         feats.record_stream(self.enc_stream)
@@ -225,11 +233,17 @@ class ViewPipeline:
         e = self.eng[b]
         if t0 is not None:
             t0.record(main)
-        view, d_done = self.pending.pop(i)
-        if encoder is not None:
-            e.scatter_encoded(view, feats, encoder, F, None if d_done else d, scale_f, scale_d)
+        view, d_done, blended = self.pending.pop(i)
+        fused = not blended and encoder is None and upsample is None and Engine.can_blend_scatter(feats)
+        if fused:
+            e.blend_scatter(view, feats, F, d, scale_f, scale_d)
         else:
-            e.scatter(view, feats, F, None if d_done else d, scale_f, scale_d, upsample=upsample)
+            if not blended:  # the map does not suit the fused kernel after all: blend here, then the usual scatter
+                e.blend_weights(view)
+            if encoder is not None:
+                e.scatter_encoded(view, feats, encoder, F, None if d_done else d, scale_f, scale_d)
+            else:
+                e.scatter(view, feats, F, None if d_done else d, scale_f, scale_d, upsample=upsample)
         if t1 is not None:
             t1.record(main)
         e.accumulate_stats(self.accum)
@@ -254,7 +268,8 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                          encoder: Optional[torch.Tensor] = None, engine: Optional[Engine] = None,
                          views: Optional[Sequence[int]] = None, view_fn=None, pipeline: bool = True,
                          return_partials: bool = False, verbose: bool = False, upsample: Optional[str] = None,
-                         gather: bool = True, allow_wide: bool = True, fuse_encoder: bool = False):
+                         gather: bool = True, allow_wide: bool = True, fuse_encoder: bool = False,
+                         fuse_small: bool = True):
     """Build the [N, dim_out] per-Gaussian feature field.
 
     means/quats/scales/opacities: post-activation Gaussians (backproject.py:55-57), device tensors.
@@ -272,6 +287,8 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     is read once, no [H,W,dim_out] intermediate) when the map's layout allows; False (default, measured faster in the
     three-stream pipeline: C5 2.19 vs 2.29 ms/view; the fused kernel wins on one stream, 2.51 vs 2.70) = a separate encode
     kernel one view ahead on a third stream (gwbp_encode_map).
+    fuse_small: maps of at most 16 channels (after the encoder) are blended AND scattered by one kernel
+    (gwbp_blend_scatter: no weight store, no scatter kernel; C5 1.96 -> 1.42 ms/view); False keeps the two-kernel form.
     pipeline: overlap the front stages of the next view(s) with the scatter of view v (ViewPipeline); True = depth chosen by
     pipeline_depth(N, width, height), an int >= 2 = that many workspaces, False = one stream.
     gather: under a process group, all-gather the finalised row blocks so that every rank returns the whole [N, dim_out]
@@ -302,7 +319,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                 # (bilinear maps are staged by the 128-channel kernel only: no wide kernel, no front priority)
                 depth = pipeline_depth(n, width, height) if pipeline is True else max(2, int(pipeline))
                 pipe = ViewPipeline(n, width, height, dev, scatter_dim=None if upsample == "bilinear" else d_out,
-                                    allow_wide=allow_wide,
+                                    allow_wide=allow_wide, fuse_small=fuse_small and not (fuse_encoder and encoder is not None),
                                     engines=[eng] + [Engine(n, width, height, device=dev, tight_binning=eng.tight_binning,
                                                             isect_cap=eng.isect_cap, pair_cap=eng.pair_cap)
                                                      for _ in range(depth - 1)])
@@ -347,7 +364,11 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                     if encoder is not None:
                         feats = eng.encode_map(feats, encoder)
                     view = eng.view(vm_host[v], K_host, width, height)
-                    if upsample is None:
+                    if upsample is None and fuse_small and Engine.can_blend_scatter(feats):
+                        eng.project(view, means, quats, scales, opacities)
+                        eng.bin_sort(view)
+                        eng.blend_scatter(view, feats, F, d, sf, sd)
+                    elif upsample is None:
                         eng.backproject_view(view, means, quats, scales, opacities, feats, F, d, sf, sd)
                     else:
                         eng.project(view, means, quats, scales, opacities)

@@ -25,16 +25,116 @@ namespace gwbp {
 
 constexpr int kBatch = 64;
 
-template <bool HALVES> // HALVES: also emit the half-tile record lists and weight sums the 256-channel scatter kernel reads
-__global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__ tile_offsets,
+// What a contributing record turns into.
+//   kStore:  entries {w, pixel} + Header in the weight store (read by k_scatter_full / k_scatter / k_render_*)
+//   kHalves: the same plus the half-tile record lists and weight sums the 256-channel scatter kernel reads
+//   kFused:  NO store: the record's sums  F[gid, :D] += sum_p w f[p, :],  d[gid] += sum_p w  are formed right here from
+//            the tile's pixels held in registers (D <= 16: 4 pixels x 16 channels = 64 VGPRs per lane) and added to F / d
+//            with one atomic instruction -- the small-D variants (backproject_compressed.py:127-165: D = 16) then need
+//            neither the 0.8 GB store nor a scatter kernel.
+enum BlendMode { kStore = 0, kHalves = 1, kFused = 2 };
+constexpr int kFusedCh = 16;
+
+struct FusedArgs { // kFused only
+    const float *feats; // feats[y * fs_y + x * fs_x + c], c < D
+    int64_t fs_y, fs_x;
+    int D;       // <= kFusedCh
+    int vec4;    // rows may be read as float4 (D % 4 == 0, 16-B aligned base and strides)
+    float scale_f;
+    float *F;
+};
+
+// Sum of 16 per-lane values over the 64 lanes, transposed: lane l returns the wave total of value c(l),
+//   c(l) = bit2(l) | bit3(l) << 1 | bit0(l) << 2 | bit1(l) << 3        (the same in all four rows of 16 lanes).
+// Each stage pairs lanes (row_half_mirror, row_ror:8, xor 1, xor 2 -- partners always agree on the earlier stages' sides,
+// together they generate all 16 lanes of a row), keeps one half of the registers on each side and adds the partner's
+// copy of the kept half: 8 + 4 + 2 + 1 outputs instead of 16 full reductions; two lane swaps add the four rows.
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float rows_sum(float v) // + the other three rows of 16 lanes (lane-wise)
+{
+#if __HIP_DEVICE_COMPILE__
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+    v = __int_as_float(a[0]) + __int_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    v = __int_as_float(b[0]) + __int_as_float(b[1]);
+#endif
+    return v;
+}
+// Stages 1 and 2 take their side from lane bits 2 and 3, i.e. from the 4-lane "bank" inside the row: the add of the second
+// half is written under a DPP bank mask, no select at all (2 instructions per output).  Stages 3 and 4 (lane bits 0 and 1)
+// select with v_cndmask under constant lane masks (3 per output).  33 vector instructions for the 16 -> 1 transposed sum;
+// written as one block because the DPP read-after-write wait states (2) are placed by hand.  p[] is clobbered.
+__device__ __forceinline__ float transposed_sum16(float (&p)[16])
+{
+#if __HIP_DEVICE_COMPILE__
+    const u64 odd = 0xAAAAAAAAAAAAAAAAull, upper2 = 0xCCCCCCCCCCCCCCCCull; // lanes with bit 0 / bit 1 set
+    asm("s_nop 1\n\t"
+        // stage 1: i <-> 7 - i (row_half_mirror); lanes 0-3, 8-11 keep the even registers, lanes 4-7, 12-15 the odd ones
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %10, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %12, %12, %12 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %14, %14, %14 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %8, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %10, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %12, %13, %13 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %14, %15, %15 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        // stage 2: i <-> i ^ 8 (row_ror:8); lanes 0-7 keep registers 0, 4, 8, 12, lanes 8-15 registers 2, 6, 10, 14
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %12, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %12, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        // stage 3: i <-> i ^ 1; even lanes keep registers 0, 8, odd lanes 4, 12
+        "v_cndmask_b32_e64 %1, %0, %4, %16\n\t"
+        "v_cndmask_b32_e64 %2, %4, %0, %16\n\t"
+        "v_cndmask_b32_e64 %3, %8, %12, %16\n\t"
+        "v_cndmask_b32_e64 %5, %12, %8, %16\n\t"
+        "v_add_f32_dpp %0, %2, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %8, %5, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        // stage 4: i <-> i ^ 2; lanes with bit 1 clear keep register 0, the others 8
+        "v_cndmask_b32_e64 %1, %0, %8, %17\n\t"
+        "v_cndmask_b32_e64 %2, %8, %0, %17\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]),
+          "+v"(p[9]), "+v"(p[10]), "+v"(p[11]), "+v"(p[12]), "+v"(p[13]), "+v"(p[14]), "+v"(p[15])
+        : "s"(odd), "s"(upper2));
+#endif
+    return rows_sum(p[0]);
+}
+__device__ __forceinline__ int transposed_channel(int lane)
+{
+    return ((lane >> 2) & 1) | (((lane >> 3) & 1) << 1) | ((lane & 1) << 2) | (((lane >> 1) & 1) << 3);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_blend(ViewDev V, const u32 *__restrict__ tile_offsets,
                                               const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
                                               Counters *__restrict__ ctr, Header *__restrict__ headers,
                                               u32 *__restrict__ hdr_count, WPair *__restrict__ wpool, u32 pair_cap,
                                               u32 *__restrict__ shards, const u32 *__restrict__ tile_order, float *__restrict__ alphas,
                                               HalfHdr *__restrict__ half_a, HalfHdr *__restrict__ half_b,
                                               u32 *__restrict__ half_cnt_a, u32 *__restrict__ half_cnt_b, int dbg, int prio,
-                                              float *__restrict__ d_out, float scale_d)
+                                              float *__restrict__ d_out, float scale_d, FusedArgs fu)
 {
+    constexpr bool HALVES = MODE == kHalves;
     front_priority(prio);
     __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
     __shared__ float4 s_b[kBatch]; // ca, cb, cc, strip mask
@@ -69,6 +169,42 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
     u32 page_pos = 0, page_left = 0, npairs = 0, hdr_n = 0; // wave-uniform
     u32 n_top = 0, n_bot = 0;                               // records with entries in tile rows 0..7 / 8..15
     bool dead = false;                                     // wave-uniform: pool exhausted
+
+    // kFused: the lane's four pixels, kFusedCh channels each, stay in registers for the whole tile (pixels outside the
+    // image never get a weight: T = 0; they read a clamped address)
+    float f[MODE == kFused ? 4 : 1][MODE == kFused ? kFusedCh : 1];
+    if constexpr (MODE == kFused) {
+        const int cx = min(ix, V.W - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float *src = fu.feats + (int64_t)min(iy0 + 4 * q, V.H - 1) * fu.fs_y + (int64_t)cx * fu.fs_x;
+            if (fu.vec4) {
+#pragma unroll
+                for (int c4 = 0; c4 < kFusedCh / 4; ++c4) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (4 * c4 < fu.D)
+                        v = reinterpret_cast<const float4 *>(src)[c4];
+                    f[q][4 * c4] = v.x, f[q][4 * c4 + 1] = v.y, f[q][4 * c4 + 2] = v.z, f[q][4 * c4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < kFusedCh; ++c)
+                    f[q][c] = c < fu.D ? src[c] : 0.f;
+            }
+        }
+    }
+    // per-lane constants of the record flush: lanes 0..15 add channel transposed_channel(lane) of F[gid], lane 16 adds d[gid]
+    const int my_ch = transposed_channel(lane);
+    float *out_base = nullptr;
+    size_t out_mul = 0;
+    float out_scale = 0.f;
+    bool out_on = false;
+    if constexpr (MODE == kFused) {
+        out_base = lane < 16 ? fu.F + my_ch : d_out;
+        out_mul = lane < 16 ? (size_t)fu.D : (size_t)1;
+        out_scale = lane < 16 ? fu.scale_f : scale_d;
+        out_on = lane < 16 ? my_ch < fu.D : (lane == 16 && d_out != nullptr);
+    }
 
     for (u32 batch = beg; batch < end; batch += kBatch) {
         // quarters that still have a live pixel; stop when the whole tile has terminated (gsplat: all threads done)
@@ -167,6 +303,36 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
                 base[q] = total;
                 total += cnt[q];
             }
+            if constexpr (MODE == kFused) {
+                float p[kFusedCh], wl = 0.f;
+#pragma unroll
+                for (int c = 0; c < kFusedCh; ++c)
+                    p[c] = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (m[q] != 0ull) { // wave-uniform
+                        float wq; // the ballot register is the select mask
+                        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(wq) : "v"(w[q]), "s"(m[q]));
+                        wl += wq;
+#pragma unroll
+                        for (int c = 0; c < kFusedCh; ++c)
+                            p[c] = __builtin_fmaf(wq, f[q][c], p[c]);
+                    }
+                const float tot = transposed_sum16(p); // every row: channel my_ch
+                wl += dpp_get<0xB1>(wl);
+                wl += dpp_get<0x4E>(wl);
+                wl += dpp_get<0x141>(wl);
+                wl += dpp_get<0x140>(wl);
+                const float ws = rows_sum(wl);
+                if (!(dbg & 1) && out_on) {
+                    // one atomic instruction: lanes 0..15 the record's channel sums, lane 16 its share of d
+                    const u32 gid = (u32)__float_as_int(a.w);
+                    atomicAdd(out_base + (size_t)gid * out_mul, (lane < 16 ? tot : ws) * out_scale);
+                }
+                ++hdr_n;
+                npairs += total;
+                continue;
+            }
             const u32 padded = (total + (kListPad - 1)) & ~(u32)(kListPad - 1);
             if (padded > page_left) {
                 u32 old = 0;
@@ -243,7 +409,7 @@ __global__ __launch_bounds__(64) void k_blend(ViewDev V, const u32 *__restrict__
         }
     }
     if (lane == 0) {
-        hdr_count[tile] = hdr_n;
+        hdr_count[tile] = MODE == kFused ? 0u : hdr_n; // kFused: the store stays empty
         if constexpr (HALVES)
             half_cnt_a[tile] = n_top, half_cnt_b[tile] = n_bot;
         if (hdr_n)
@@ -308,9 +474,22 @@ __global__ void k_pool_stats(const u32 *__restrict__ shards, Counters *__restric
     ctr->pool_head = mx * (u32)kShards;
 }
 
-int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, float *d, float scale_d, hipStream_t s)
+int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, float *d, float scale_d, hipStream_t s,
+                 const FeatMap *M, int D, float scale_f, float *F)
 {
-    if (d && (L.flags & GWBP_FLAG_NARROW_SCATTER))
+    const bool fused = M != nullptr;
+    FusedArgs fu = {};
+    if (fused) {
+        if (D < 1 || D > kFusedCh)
+            return set_error(GWBP_EINVAL, "gwbp_blend_scatter: D must be 1..%d (got %d)", kFusedCh, D);
+        if (M->fs_c != 1 || M->ymap || M->xmap || M->enc)
+            return set_error(GWBP_EINVAL, "gwbp_blend_scatter: a full-resolution map with unit channel stride is required");
+        if (!M->p || !F)
+            return set_error(GWBP_EINVAL, "null feats / F");
+        fu.feats = M->p, fu.fs_y = M->fs_y, fu.fs_x = M->fs_x, fu.D = D, fu.scale_f = scale_f, fu.F = F;
+        fu.vec4 = (D % 4 == 0 && M->fs_y % 4 == 0 && M->fs_x % 4 == 0 && (reinterpret_cast<uintptr_t>(M->p) & 15) == 0) ? 1 : 0;
+    }
+    if (!fused && d && (L.flags & GWBP_FLAG_NARROW_SCATTER))
         return set_error(GWBP_EINVAL, "gwbp_blend_weights_d needs a blend without GWBP_FLAG_NARROW_SCATTER (no weight sums)");
     const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
     const int n_tiles = V.tile_w * V.tile_h;
@@ -321,14 +500,16 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
 #define GWBP_BLEND(H)                                                                                                 \
     hipLaunchKernelGGL(k_blend<H>, dim3(n_tiles), dim3(64), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d,  \
                        W.counters, W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, W.tile_order, alphas,  \
-                       W.half[0], W.half[1], W.half_count[0], W.half_count[1], ablate, prio, d, scale_d)
-    if (L.flags & GWBP_FLAG_NARROW_SCATTER)
-        GWBP_BLEND(false);
+                       W.half[0], W.half[1], W.half_count[0], W.half_count[1], ablate, prio, d, scale_d, fu)
+    if (fused)
+        GWBP_BLEND(kFused);
+    else if (L.flags & GWBP_FLAG_NARROW_SCATTER)
+        GWBP_BLEND(kStore);
     else
-        GWBP_BLEND(true);
+        GWBP_BLEND(kHalves);
 #undef GWBP_BLEND
     hipLaunchKernelGGL(k_pool_stats, dim3(1), dim3(1), 0, s, W.shards, W.counters,
-                       (L.flags & GWBP_FLAG_NARROW_SCATTER) ? 0u : kBlendHalves);
+                       fused ? kBlendFused : (L.flags & GWBP_FLAG_NARROW_SCATTER) ? 0u : kBlendHalves);
     return check_hip(hipGetLastError(), "blend launch");
 }
 

@@ -306,6 +306,22 @@ int gwbp_blend_weights_d(const gwbp_caps *caps, void *workspace, size_t workspac
     return launch_blend(L, W, V, alphas, d, scale_d, static_cast<hipStream_t>(stream));
 }
 
+int gwbp_blend_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                       const float *feats, int64_t fs_y, int64_t fs_x, int32_t D, float scale_f, float scale_d, float *F,
+                       float *d, float *alphas, void *stream)
+{
+    Layout L;
+    Ws W;
+    ViewDev V;
+    int rc = bind_workspace(caps, workspace, workspace_bytes, &L, &W);
+    if (rc)
+        return rc;
+    if ((rc = make_view(view_host, caps, &V)))
+        return rc;
+    const FeatMap M{feats, fs_y, fs_x, 1, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    return launch_blend(L, W, V, alphas, d, scale_d, static_cast<hipStream_t>(stream), &M, D, scale_f, F);
+}
+
 int gwbp_accumulate_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                       float scale_d, float *d, void *stream)
 {

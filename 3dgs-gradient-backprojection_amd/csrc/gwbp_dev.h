@@ -79,6 +79,7 @@ struct Counters {
     u32 blend_kind; // gwbp_stats::reserved: kBlendHalves once k_blend<true> has written the half-tile lists of THIS view
 };
 constexpr u32 kBlendHalves = 1u;
+constexpr u32 kBlendFused = 2u; // gwbp_blend_scatter: the view was blended AND scattered, its weight store is empty
 constexpr u32 kOverflowMismatch = 4u; // gwbp_stats::overflow bit 2, see include/gwbp.h
 static_assert(sizeof(Counters) == sizeof(gwbp_stats), "Counters must mirror gwbp_stats");
 
@@ -149,7 +150,10 @@ int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *
 int launch_emit(const Layout &L, const Ws &W, const ViewDev &V, const u32 *order, hipStream_t s);
 int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *isect_ids, int32_t *flatten_ids,
                     int32_t *tile_offsets, hipStream_t s);
-int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, float *d, float scale_d, hipStream_t s);
+struct FeatMap;
+// M != nullptr: the fused small-D form (gwbp_blend_scatter): F[gid, :D] and d are accumulated by the blend itself
+int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, float *d, float scale_d, hipStream_t s,
+                 const FeatMap *M = nullptr, int D = 0, float scale_f = 1.0f, float *F = nullptr);
 // A 2-D feature map as the scatter kernels address it: feats[row(y)*fs_y + col(x)*fs_x + c*fs_c] (strides in floats).
 // ymap/xmap (device, optional) send an output pixel to the row/column of a lower-resolution map: the
 // F.interpolate(mode="nearest") of backproject.py:244-248 without materialising the upsampled map.  With ly/lx as well

@@ -177,6 +177,30 @@ class Engine:
         self._call("gwbp_blend_weights", *self._args(), C.byref(view), ptr(alphas), self._stream())
         return alphas
 
+    FUSED_MAX_DIM = 16  # gwbp_blend_scatter holds 4 pixels x 16 channels per lane in registers
+
+    @classmethod
+    def can_blend_scatter(cls, feats: torch.Tensor) -> bool:
+        """Maps gwbp_blend_scatter takes: [H,W,D] float32, D <= 16, unit channel stride, non-negative strides."""
+        return (feats.dim() == 3 and feats.is_cuda and feats.dtype == torch.float32 and 1 <= feats.shape[2] <= cls.FUSED_MAX_DIM
+                and feats.stride(2) == 1 and min(feats.stride()) >= 0)
+
+    def blend_scatter(self, view, feats, F, d, scale_f=1.0, scale_d=1.0, want_alphas=False):
+        """blend_weights + scatter of one view in ONE kernel for narrow maps (D <= 16: the compressed variant after its
+        encoder, backproject_compressed.py:127-165): the tile's pixels sit in registers while it is blended, each
+        contributing record is reduced across the wave and added to F / d at once.  No weight store is written: the
+        view cannot be scattered or rendered again without a new blend_weights()."""
+        if not self.can_blend_scatter(feats):
+            raise GwbpError(f"blend_scatter: [H,W,D<={self.FUSED_MAX_DIM}] float32 map with unit channel stride required, "
+                            f"got {tuple(feats.shape)} strides {tuple(feats.stride())}")
+        sy, sx, _, D = self._feat_strides(feats, view)
+        self._check_acc(F, d, D)
+        alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
+        self._halves = False  # the store is empty: neither scatter kernel has anything to read
+        self._call("gwbp_blend_scatter", *self._args(), C.byref(view), ptr(feats), sy, sx, D, C.c_float(scale_f),
+                   C.c_float(scale_d), ptr(F), ptr(d), ptr(alphas), self._stream())
+        return alphas
+
     @staticmethod
     def _feat_strides(feats: torch.Tensor, view, lowres: bool = False) -> Tuple[int, int, int, int]:
         if feats.dim() != 3 or (not lowres and (feats.shape[0] != view.height or feats.shape[1] != view.width)):

@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
     ap.add_argument("--exact-binning", action="store_true",
                     help="gsplat's 3-sigma tile binning instead of GWBP_FLAG_TIGHT_BINNING (same F and d either way)")
+    ap.add_argument("--no-fuse-small", action="store_true",
+                    help="D <= 16: keep blend (weight store) and scatter as two kernels instead of gwbp_blend_scatter")
     ap.add_argument("--serial", action="store_true", help="one stream, no overlap of front(v+1) with scatter(v)")
     args = ap.parse_args()
 
@@ -123,13 +125,16 @@ def main():
                 for _ in range(depth - 1)]
         pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng] + more, scatter_dim=D, allow_wide=allow_wide,
                                      scatter_workgroups=args.pipe_wgs, side_priority=args.side_prio,
-                                     front_priority=None if args.front_prio == "auto" else args.front_prio == "on")
+                                     front_priority=None if args.front_prio == "auto" else args.front_prio == "on",
+                                     fuse_small=not args.no_fuse_small)
         accum = pipe.accum
         if args.enc_wgs_per_cu:
             pipe.ENCODER_WORKGROUPS_PER_CU = args.enc_wgs_per_cu
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     n_total = args.steps + args.warmup
+    # D <= 16: blend + scatter in one kernel (gwbp_blend_scatter), the front stage ends with the sort
+    fused_small = D <= gsbp_amd.Engine.FUSED_MAX_DIM and not args.no_fuse_small and args.encoder != "fused"
 
     def front(i):
         """project -> bin/sort -> blend of view i on the side stream (overlaps scatter of view i-1)."""
@@ -164,6 +169,14 @@ def main():
         if args.serial:  # one stream, one workspace: the pre-pipelining schedule
             eng.project(views[i], means, quats, scales, opac)
             eng.bin_sort(views[i])
+            if fused_small and fenc is None:
+                if 0 <= k < args.steps:
+                    ev[k][2].record()
+                eng.blend_scatter(views[i], feats, F, d)
+                eng.accumulate_stats(accum)
+                if 0 <= k < args.steps:
+                    ev[k][3].record()
+                return
             eng.blend_weights(views[i])
             if 0 <= k < args.steps:
                 ev[k][2].record()
@@ -268,7 +281,8 @@ def main():
                 traffic_source = "profiles/traffic.json (" + str(tj.get("source", "rocprofv3 --pmc, earlier run")) + ")"
             except Exception:
                 traffic = None
-        scatter_kernel = ("k_scatter_wide" if scatter_choice == "wide" else
+        scatter_kernel = ("k_blend<kFused> (blend + scatter in one kernel, no weight store)" if fused_small else
+                          "k_scatter_wide" if scatter_choice == "wide" else
                           "k_scatter_full" if (D % 128 == 0 or D <= 64) else "k_scatter")
         out = {
             "metric": "Gaussian-pixel-features/sec", "value": total_pairs * D / elapsed,
@@ -285,8 +299,9 @@ def main():
                        "schedule": "serial" if args.serial else
                        f"front(v+1..v+{pipe.lookahead}) overlapped with scatter(v): {1 + len(pipe.sides)} streams, "
                        f"{len(pipe.eng)} workspaces",
-                       "stage_ms": {"front(project+sort+blend, side stream, overlapped)": t_front,
-                                    "scatter": t_scatter}},
+                       "stage_ms": {("front(project+sort, side stream, overlapped)" if fused_small else
+                                     "front(project+sort+blend, side stream, overlapped)"): t_front,
+                                    "blend+scatter" if fused_small else "scatter": t_scatter}},
             "roofline": {"bound": "hbm", "kernel": scatter_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,

@@ -127,6 +127,17 @@ int gwbp_blend_weights(const gwbp_caps *caps, void *workspace, size_t workspace_
 int gwbp_blend_weights_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                          float *alphas, float scale_d, float *d, void *stream);
 
+/* Blend AND scatter of one view in one kernel, for narrow maps (1 <= D <= 16: backproject_compressed.py:127-165 after its
+ * 512 -> 16 encoder; a 3-channel colour gradient): while a tile is blended its 256 pixels x D channels sit in registers,
+ * each contributing (Gaussian, tile) record's sums  F[g, :D] += scale_f * sum_p w f[p, :],  d[g] += scale_d * sum_p w  are
+ * reduced across the wave and added with one atomic instruction.  No weight store is written (the workspace's store is
+ * left EMPTY: a later gwbp_scatter / gwbp_render of this view adds nothing and gwbp_stats.reserved reads 2), no scatter
+ * kernel runs.  feats[y * fs_y + x * fs_x + c] full resolution, unit channel stride; d may be NULL; alphas optional.
+ * The weights are those of gwbp_blend_weights bit for bit; F and d differ from gwbp_scatter's only by summation order. */
+int gwbp_blend_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                       const float *feats, int64_t fs_y, int64_t fs_x, int32_t D, float scale_f, float scale_d,
+                       float *F, float *d, float *alphas, void *stream);
+
 /* d[g] += scale_d * sum_p w_g(p) alone, from the per-record weight sums gwbp_blend_weights left in the workspace
  * (needs a blend WITHOUT GWBP_FLAG_NARROW_SCATTER).  A caller that overlaps the front stage of view v+1 with the
  * scatter of view v issues it behind the blend on the front's stream and passes d = NULL to gwbp_scatter: the

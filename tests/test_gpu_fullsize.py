@@ -242,7 +242,14 @@ def test_c5_full_size_encoder_path_against_oracle(dev, orc):
     assert st2["overflow"] == 0 and st2["n_pairs"] == st["n_pairs"]
     assert float((F2 - F).norm(dim=1).max()) <= 2e-5 * float(F.norm(dim=1).max())
     assert float((d2 - d).abs().max()) <= 2e-5 * float(d.max())
-    del F2, d2
+    # ... and as separate blend (weight store) + small-D scatter kernels instead of the fused gwbp_blend_scatter
+    _, F3, d3, st3 = gsbp_amd.create_feature_field(*g, vms.to(dev), K.to(dev), cfg.width, cfg.height, lambda v: maps[v],
+                                                   cfg.feat_dim, encoder=enc.to(dev), return_partials=True,
+                                                   fuse_small=False)
+    assert st3["overflow"] == 0 and st3["n_pairs"] == st["n_pairs"] and st3["n_headers"] == st["n_headers"]
+    assert float((F3 - F).norm(dim=1).max()) <= 2e-5 * float(F.norm(dim=1).max())
+    assert float((d3 - d).abs().max()) <= 2e-5 * float(d.max())
+    del F2, d2, F3, d3
     Fr, dr, pairs = _oracle_views(orc, cfg, [t.numpy() for t in g_cpu], vms, K,
                                   [lambda v=v: (maps[v].cpu() @ enc).numpy() for v in range(V)], cfg.encoder_dim)
     assert st["n_pairs"] == pairs

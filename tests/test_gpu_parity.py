@@ -107,6 +107,44 @@ def test_scatter_parity(name, D, wide, orc, dev):
     assert np.array_equal(out[dr == 0], np.zeros_like(out[dr == 0]))  # NaN -> 0 rows (backproject.py:169)
 
 
+@pytest.mark.parametrize("name,D", [("T0", 16), ("T0", 3), ("T1", 16), ("T1", 5), ("T1", 8), ("C1", 16), ("C1", 1)])
+def test_blend_scatter_fused_parity(name, D, orc, dev):
+    """gwbp_blend_scatter (D <= 16): blend and scatter in one kernel, no weight store -- same F, d, alphas, counters."""
+    cfg, sc = scene_np(name)
+    d, h = to_dev(sc, dev), npy(sc)
+    eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev)
+    F = torch.zeros(cfg.n_gaussians, D, device=dev)
+    dd = torch.zeros(cfg.n_gaussians, device=dev)
+    Fr = np.zeros((cfg.n_gaussians, D), np.float64)
+    dr = np.zeros(cfg.n_gaussians, np.float64)
+    for v in range(cfg.n_views):
+        feats = syn.make_feature_map(cfg, v, dim=D)
+        fd = feats.to(dev)
+        if v % 2 == 1:  # a pixel stride that is not a multiple of 4 floats: the scalar-load path
+            wide = torch.zeros(cfg.height, cfg.width, D + 1, device=dev)
+            wide[..., :D] = fd
+            fd = wide[..., :D]
+        view = eng.view(d["vms"][v], d["K"], cfg.width, cfg.height)
+        eng.project(view, d["means"], d["quats"], d["scales"], d["opac"])
+        eng.bin_sort(view)
+        alphas = eng.blend_scatter(view, fd, F, dd, want_alphas=True)
+        st = eng.stats()
+        assert st["overflow"] == 0
+        ref_p = orc.project(h["means"], h["quats"], h["scales"], h["vms"][v], h["K"], cfg.width, cfg.height)
+        ref_b = orc.bin_sort(ref_p, cfg.width, cfg.height)
+        _, _, _, ralpha = orc.blend_pairs(ref_p, ref_b, h["opac"], cfg.width, cfg.height, want_alphas=True)
+        info = orc.backproject_view(h["means"], h["quats"], h["scales"], h["opac"], h["vms"][v], h["K"], cfg.width,
+                                    cfg.height, feats.numpy(), Fr, dr)
+        assert st["n_pairs"] == info["n_pairs"] and st["n_isect"] == info["n_isect"]
+        assert np.array_equal(alphas.cpu().numpy().view(np.uint32), ralpha.view(np.uint32))
+        # the store is empty: scattering the view again adds nothing
+        F2, d2 = torch.zeros_like(F), torch.zeros_like(dd)
+        eng.scatter(view, fd, F2, d2)
+        assert not F2.any() and not d2.any()
+    assert rel_row_err(F.cpu().numpy(), Fr) <= TOL
+    assert rel_row_err(dd.cpu().numpy()[:, None], dr[:, None]) <= TOL
+
+
 def test_scatter_strided_feature_map(orc, dev):
     """backproject.py:113 hands a permuted [D,H,W] view as feats; strides travel through the C ABI."""
     cfg, sc = scene_np("T0")
