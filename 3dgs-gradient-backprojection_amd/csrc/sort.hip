@@ -123,10 +123,12 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u32 *__res
     }
     __syncthreads();
 
-    // Only {rank, digit} of an item survives the two barriers (one packed dword); keys and values are re-read for the
-    // scatter (the block's 16 KB are L2-resident).  Holding key[16] + val[16] + rank[16] put the kernel at 106 VGPRs: one
-    // block per CU beside the persistent scatter workgroup, where each pass then took 200-260 us instead of 30.
-    u32 rd[kItemsPerThread]; // rank | digit << 16   (rank < 4096)
+    // Only the rank of an item survives the two barriers; keys (hence digits) and values are re-read for the scatter (the
+    // block's 16 KB are L2-resident): 60 VGPRs.  Holding key[16] + val[16] + rank[16] put the kernel at 106: one block per
+    // CU beside the persistent scatter workgroup, where each pass then took 200-260 us instead of 30.  (Ranks parked in
+    // LDS as u16 instead -- 19 VGPRs, 13 KB -- were measured too: 4 % slower alone, and no faster step beside the fused
+    // blend+scatter kernel, whose four 120-VGPR waves per SIMD leave this kernel no register room.)
+    u32 r_rank[kItemsPerThread];
     const u32 seg = base + wave * (u32)kWaveItems;
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u32 *__res
             s_cnt[wave][dg] = old + (u32)__popcll(peers);
         }
         old = __shfl(old, leader, 64);
-        rd[it] = (old + (u32)__popcll(peers & lt)) | (dg << 16);
+        r_rank[it] = old + (u32)__popcll(peers & lt);
     }
     __syncthreads();
     { // thread = digit: turn per-wave counts into global bases
@@ -167,8 +169,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u32 *__res
     for (int it = 0; it < kItemsPerThread; ++it) {
         const u32 idx = seg + it * 64 + lane;
         if (idx < n) {
-            const u32 pos = s_cnt[wave][rd[it] >> 16] + (rd[it] & 0xFFFFu);
-            keys_out[pos] = keys_in[idx];
+            const u32 key = keys_in[idx];
+            const u32 pos = s_cnt[wave][(key >> shift) & 0xFFu] + r_rank[it];
+            keys_out[pos] = key;
             vals_out[pos] = vals_in[idx];
         }
     }
