@@ -124,6 +124,15 @@ __device__ __forceinline__ int transposed_channel(int lane)
     return ((lane >> 2) & 1) | (((lane >> 3) & 1) << 1) | ((lane & 1) << 2) | (((lane >> 1) & 1) << 3);
 }
 
+// lane-wise  mask bit ? a : b  with a lane mask that lives in an SGPR pair (one v_cndmask; spelled in C the compiler
+// rebuilds a per-lane bool from the mask with two v_and and a 64-bit compare)
+__device__ __forceinline__ float mask_select(u64 mask, float a, float b)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_blend(ViewDev V, const u32 *__restrict__ tile_offsets,
                                               const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
@@ -271,17 +280,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     // no live pixel of this quarter lies inside the alpha >= 1/255 ellipse: skip exp / T / ballot
                     if (__ballot(T[q] > 0.f && sigma <= thr) == 0ull)
                         continue;
-                    const float alpha = __builtin_fminf(kAlphaMax, a.z * exp_neg(-__builtin_fmaxf(sigma, 0.f)));
-                    const float a1 = sigma >= 0.f ? alpha : 0.f;            // sigma < 0: skipped
-                    const bool ok = a1 >= kAlphaMin;                         // alpha < 1/255: skipped
+                    const float alpha = __builtin_fminf(kAlphaMax, a.z * exp_neg_sigma(sigma));
+                    // The three tests as lane masks (a ballot of a COMPARE is that compare's own SGPR result; a ballot of
+                    // their conjunction costs v_cndmask + v_cmp_ne), combined on the scalar unit.
                     const float next_T = T[q] * (1.0f - alpha);
-                    const float t = ok ? next_T : 0.f;
-                    const bool valid = t > kTMin;                            // T' <= 1e-4: terminates, NOT counted
-                    const float T_else = ok ? 0.f : T[q];                    // ok but not valid -> terminated
+                    const u64 m_ok = __builtin_amdgcn_ballot_w64(sigma >= 0.f) &       // sigma < 0: skipped
+                                     __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin);  // alpha < 1/255: skipped
+                    const u64 m_valid = m_ok & __builtin_amdgcn_ballot_w64(next_T > kTMin); // T' <= 1e-4: terminates, NOT counted
+                    const float T_else = mask_select(m_ok, 0.f, T[q]);       // ok but not valid -> terminated
                     w[q] = alpha * T[q];
-                    T[q] = valid ? next_T : T_else;
-                    Tout[q] = valid ? next_T : Tout[q];
-                    m[q] = __ballot(valid);
+                    T[q] = mask_select(m_valid, next_T, T_else);
+                    Tout[q] = mask_select(m_valid, next_T, Tout[q]);
+                    m[q] = m_valid;
                 }
             }
             if ((m[0] | m[1] | m[2] | m[3]) == 0ull) {

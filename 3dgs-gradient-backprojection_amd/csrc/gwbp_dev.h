@@ -217,9 +217,8 @@ __device__ __forceinline__ float dot3f(float a0, float a1, float a2, float b0, f
 
 // exp(x), x <= 0: ln2 hi/lo range reduction, degree-7 Taylor (Horner, fma), exponent added to the bit pattern.
 // Deterministic (no v_exp_f32), so weights do not depend on a transcendental unit; ~12 VALU ops.
-__device__ __forceinline__ float exp_neg(float x)
+__device__ __forceinline__ float exp_neg_core(float x) // -80 <= x <= 0
 {
-    x = __builtin_fmaxf(x, -80.0f);
     const float t = x * 0x1.715476p+0f;
     const float n = __builtin_rintf(t);
     float r = __builtin_fmaf(n, -0x1.62e4p-1f, x);
@@ -233,6 +232,16 @@ __device__ __forceinline__ float exp_neg(float x)
     p = __builtin_fmaf(p, r, 1.0f);
     p = __builtin_fmaf(p, r, 1.0f);
     return __int_as_float(__float_as_int(p) + (((int)n) << 23));
+}
+__device__ __forceinline__ float exp_neg(float x)
+{
+    return exp_neg_core(__builtin_fmaxf(x, -80.0f));
+}
+// exp_neg(-fmaxf(sigma, 0)) bit for bit with ONE clamp instruction: med3(-sigma, 0, -80) is -sigma inside [0, 80], 0 below
+// (exp of either zero is 1.0) and -80 above; fmaxf twice costs three (each with a canonicalising v_max in front).
+__device__ __forceinline__ float exp_neg_sigma(float sigma)
+{
+    return exp_neg_core(__builtin_amdgcn_fmed3f(-sigma, 0.0f, -80.0f));
 }
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
