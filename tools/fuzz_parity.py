@@ -20,6 +20,7 @@ dev = torch.device("cuda:0")
 orc.build()
 DIMS = [1, 3, 4, 7, 8, 12, 16, 17, 32, 40, 64, 65, 100, 128, 130, 256, 384, 512, 768]
 bad = 0
+n_fused = 0
 t0 = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
@@ -69,13 +70,19 @@ for case in range(n_cases):
     F = torch.zeros(n, D, device=dev)
     d = torch.zeros(n, device=dev)
     view = eng.view(vm, K, W, H)
-    if up is None:
+    fused = up is None and bool(rng.integers(0, 2)) and gsbp_amd.Engine.can_blend_scatter(fd)
+    if fused:  # D <= 16, unit channel stride: blend + scatter in one kernel (gwbp_blend_scatter)
+        eng.project(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
+        eng.bin_sort(view)
+        eng.blend_scatter(view, fd, F, d)
+    elif up is None:
         eng.backproject_view(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev), fd, F, d)
     else:
         eng.project(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
         eng.bin_sort(view)
         eng.blend_weights(view)
         eng.scatter(view, fd, F, d, upsample=str(up))
+    n_fused += int(fused)
     st = eng.stats()
     Fr, dr = np.zeros((n, D), np.float64), np.zeros(n, np.float64)
     info = orc.backproject_view(means.numpy(), quats.numpy(), scales.numpy(), opac.numpy(), vm.numpy(), K.numpy(), W, H,
@@ -86,7 +93,7 @@ for case in range(n_cases):
     ok = ok and eF <= 1e-4 and ed <= 1e-4 and (tight or st["n_isect"] == info["n_isect"])
     if not ok:
         bad += 1
-        print(f"FAIL case {seed0 + case}: N={n} {W}x{H} D={D} s0={s0:.4f} {layout} up={up} wide={wide} tight={tight} "
+        print(f"FAIL case {seed0 + case}: N={n} {W}x{H} D={D} s0={s0:.4f} {layout} up={up} wide={wide} tight={tight} fused={fused} "
               f"pairs {st['n_pairs']}/{info['n_pairs']} eF={eF:.2e} ed={ed:.2e} overflow={st['overflow']}", flush=True)
-print(f"{n_cases} cases, {bad} failures, {time.time() - t0:.0f} s")
+print(f"{n_cases} cases ({n_fused} through the fused blend+scatter kernel), {bad} failures, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
