@@ -44,6 +44,7 @@ __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ w
     const unsigned lane_base = lane * 8;
     float2 acc = make_float2(0.f, 0.f);
     float2 acc2 = make_float2(0.f, 0.f);
+    unsigned long long smask = 0;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -239,6 +240,28 @@ __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ w
                     asm volatile("ds_read_b128 %0, %1" : "=v"(g[j]) : "v"(a));
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if (MODE == 14) {
+                // mode 5 with the pixel index taken from the record's pixel MASK by a scalar bit scan (s_ff1 + s_bitset0 per
+                // pair on the scalar unit) instead of a second v_readlane: 4 vector instructions per pair instead of 5
+                float4 g[8];
+                if (b == 0)
+                    smask = __builtin_amdgcn_readfirstlane(pv) * 0x9E3779B97F4A7C15ull | 0xFFFFFFFFull; // >= 32 bits set
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int p;
+                    asm volatile("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(p), "+s"(smask));
+                    g[j] = lds_read_b128((unsigned)(((p & 31) << 10) + lane * 16));
+                }
+                if (b == 3) // 32 pairs per refill in this benchmark (a half-tile record averages 24)
+                    smask = __builtin_amdgcn_readfirstlane(pv + b) * 0x9E3779B97F4A7C15ull | 0xFFFFFFFFull;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float w = rl_f(wv, 8 * b + j);
+                    acc.x = __builtin_fmaf(w, g[j].x, acc.x);
+                    acc.y = __builtin_fmaf(w, g[j].y, acc.y);
+                    acc2.x = __builtin_fmaf(w, g[j].z, acc2.x);
+                    acc2.y = __builtin_fmaf(w, g[j].w, acc2.y);
+                }
             } else if (MODE == 5) {
                 float4 g[8];
 #pragma unroll
@@ -319,6 +342,7 @@ int main()
     run<7>("7 LDS bcast b128/2pairs + ...", iters, w, p, out);
     run<10>("10 mode 5, 2 batches of 4 in flight", iters, w, p, out, 2.0);
     run<11>("11 mode 5, 2 batches of 8 in flight", iters, w, p, out, 2.0);
+    run<14>("14 mode 5, pixel by scalar bit scan", iters, w, p, out, 2.0);
     run<12>("12 ds_read_b128 only, fixed addresses", iters, w, p, out, 2.0);
     run<13>("13 ds_read_b128 only, readlane addresses", iters, w, p, out, 2.0);
     run<8>("8 2 pairs/instr: b64 ent + add + b128 + 2pkfma", iters, w, p, out, 2.0);
