@@ -133,6 +133,21 @@ __device__ __forceinline__ float mask_select(u64 mask, float a, float b)
     return r;
 }
 
+// One 8-B store per lane whose bit is set in `mask`: exec IS the ballot mask.  (`if ((mask >> lane) & 1)` makes the compiler
+// rebuild the predicate per lane: two v_and, a 64-bit compare and a saveexec per quarter.)
+__device__ __forceinline__ void store_pair_masked(u64 mask, WPair *dst, const WPair &e)
+{
+    u64 saved;
+    const u64 bits = ((u64)e.pix << 32) | (u64)(u32)__float_as_int(e.w);
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "global_store_dwordx2 %2, %3, off\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "s"(mask), "v"(dst), "v"(bits)
+                 : "memory");
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_blend(ViewDev V, const u32 *__restrict__ tile_offsets,
                                               const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
@@ -321,8 +336,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (m[q] != 0ull) { // wave-uniform
-                        float wq; // the ballot register is the select mask
-                        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(wq) : "v"(w[q]), "s"(m[q]));
+                        const float wq = mask_select(m[q], w[q], 0.f); // the ballot register is the select mask
                         wl += wq;
 #pragma unroll
                         for (int c = 0; c < kFusedCh; ++c)
@@ -359,12 +373,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
             if (!dead && !(dbg & 1)) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if ((m[q] >> lane) & 1ull) { // exec = the quarter's ballot mask
-                        WPair e;
-                        e.w = w[q], e.pix = (u32)(q * 64 + lane);
-                        wpool[page_pos + base[q] + mbcnt(m[q])] = e;
-                    }
+                for (int q = 0; q < 4; ++q) { // exec = the quarter's ballot mask
+                    WPair e;
+                    e.w = w[q], e.pix = (u32)(q * 64 + lane);
+                    store_pair_masked(m[q], wpool + (page_pos + base[q] + mbcnt(m[q])), e);
+                }
                 if ((u32)lane < padded - total) { // {0, 0} tail: the scatter loop needs no remainder handling
                     WPair z;
                     z.w = 0.f, z.pix = 0u;
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     float wl = 0.f;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        wl += ((m[q] >> lane) & 1ull) ? w[q] : 0.f;
+                        wl += mask_select(m[q], w[q], 0.f);
                     wsum = wave_sum(wl);
                 }
                 if (lane == 0) {
@@ -390,8 +403,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     h.mask[0] = m[0], h.mask[1] = m[1], h.mask[2] = m[2], h.mask[3] = m[3];
                     headers[beg + hdr_n] = h;
                     if constexpr (HALVES) { // gwbp_blend_weights_d: the record's share of d[gid] right here (no k_accum_d)
-                        if (d_out)
-                            atomicAdd(d_out + h.gid, wsum * scale_d);
+                        if (d_out) // (spelled as the instruction: hipcc wraps a single-lane atomicAdd in its wave-aggregation code)
+                            asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(d_out + h.gid), "v"(wsum * scale_d) : "memory");
                     }
                     // the same record as (up to) two half-tile visits for k_scatter_wide
                     const u32 ct = HALVES ? cnt[0] + cnt[1] : 0u, cb = HALVES ? cnt[2] + cnt[3] : 0u;

@@ -91,7 +91,7 @@ typedef struct gwbp_stats {
                            * bit2: gwbp_scatter / gwbp_accumulate_d asked for the 256-channel kernel on a view that was
                            * blended WITH GWBP_FLAG_NARROW_SCATTER (no half-tile lists / weight sums): that call left
                            * F and d untouched -- scatter again with the flag set */
-    uint32_t reserved;    /* 1 once gwbp_blend_weights has written the half-tile lists of this view */
+    uint32_t reserved;    /* what the last blend of this view left: 0 = weight store, 1 = store + half-tile lists, 2 = nothing (gwbp_blend_scatter) */
 } gwbp_stats;
 
 /* Library / build identification ("gfx950;<git-less build tag>"). */
