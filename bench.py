@@ -134,7 +134,8 @@ def main():
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     n_total = args.steps + args.warmup
     # D <= 16: blend + scatter in one kernel (gwbp_blend_scatter), the front stage ends with the sort
-    fused_small = D <= gsbp_amd.Engine.FUSED_MAX_DIM and not args.no_fuse_small and args.encoder != "fused"
+    fused_small = (D <= gsbp_amd.Engine.FUSED_MAX_DIM and not args.no_fuse_small and args.encoder != "fused"
+                   and (args.serial or pipe.fuse_small))
 
     def front(i):
         """project -> bin/sort -> blend of view i on the side stream (overlaps scatter of view i-1)."""
