@@ -60,6 +60,7 @@ class Engine:
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
             raise GwbpError("Engine needs a HIP device (there is no CPU path)")
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.lib = _lib.lib()
         self._maps: Dict[Tuple[int, int, int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
         self.n = int(n_gaussians)
@@ -120,8 +121,12 @@ class Engine:
     def _call(self, name: str, *args):
         """One C-ABI call with this engine's device current: libgwbp launches on the CURRENT HIP device, while the
         workspace, the tensors and the stream handle belong to self.device (a process may hold engines on several)."""
+        fn = getattr(self.lib, name)
+        if torch.cuda.current_device() == self._dev_index:  # the usual case: no device switch (a context manager costs
+            check(fn(*args), name)                           # ~10 us per call, and small scenes are host-bound)
+            return
         with torch.cuda.device(self.device):
-            check(getattr(self.lib, name)(*args), name)
+            check(fn(*args), name)
 
     def _args(self):
         return C.byref(self.caps), self._ws_ptr, C.c_size_t(self.ws_bytes)

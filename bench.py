@@ -232,6 +232,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run_views(args.warmup, n_total)  # the whole of every timed view, its front stage included, lies in the region
+    t_enqueue = time.perf_counter() - t0  # host time to enqueue the timed views (small scenes: is the host the limit?)
     F_rows, d_sum, row0 = F, d, 0
     if use_dist:
         # the path's one exchange step, inside the timed region: reduce-scatter of F (rank r keeps the rows it would
@@ -296,7 +297,7 @@ def main():
                        "views_per_sec": world * args.steps / elapsed, "pairs_per_view": pairs_view,
                        "n_visible_per_view": n_vis, "n_isect_per_view": n_isect, "n_headers_per_view": n_hdr,
                        "binning": "alpha-ellipse bounding box (GWBP_FLAG_TIGHT_BINNING)" if tight else "gsplat 3-sigma square",
-                       "overflow": overflow,
+                       "overflow": overflow, "host_enqueue_ms_per_view": t_enqueue * 1e3 / args.steps,
                        "schedule": "serial" if args.serial else
                        f"front(v+1..v+{pipe.lookahead}) overlapped with scatter(v): {1 + len(pipe.sides)} streams, "
                        f"{len(pipe.eng)} workspaces",
