@@ -177,6 +177,120 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u32 *__res
     }
 }
 
+// Small scenes (N <= 12 K Gaussians): the whole level-1 sort -- four 8-bit passes over (depth key, index) -- in ONE
+// workgroup with the pairs resident in LDS, instead of 4 x (k_hist, k_scan, k_radix_scatter) = 12 launches of 5-15 us each.
+// A view of such a scene is a chain of dependent launches that the HOST can barely enqueue fast enough (bench.py C1:
+// host_enqueue_ms_per_view = 0.17 of a 0.18 ms step), so every launch removed is time.  Same ranking scheme as
+// k_radix_scatter (wave-striped ballot match, per-wave digit counters): the result is the same stable order bit for bit.
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallWaves = kSmallThreads / 64;
+constexpr int kSmallMaxItems = 12 * kSmallThreads; // 12 items per thread: 103 VGPRs (16: 128 + spills)
+
+template <int IPT> // items per thread: N <= IPT * 1024
+__global__ __launch_bounds__(kSmallThreads) void k_sort_small(u32 *__restrict__ keys, u32 *__restrict__ vals, u32 n, int prio)
+{
+    front_priority(prio);
+    extern __shared__ u32 s_small[];
+    u32 *kbuf = s_small, *vbuf = s_small + IPT * kSmallThreads;
+    u32(*s_cnt)[256] = reinterpret_cast<u32(*)[256]>(vbuf + IPT * kSmallThreads); // [wave][digit]
+    u32 *s_w = reinterpret_cast<u32 *>(s_cnt + kSmallWaves);                        // 4 wave totals of the digit scan
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 seg = (u32)wave * (u32)(IPT * 64);
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+        const u32 idx = seg + it * 64 + lane;
+        kbuf[idx] = idx < n ? keys[idx] : ~0u;
+        vbuf[idx] = idx < n ? vals[idx] : 0u;
+    }
+    for (int shift = 0; shift < 32; shift += 8) {
+#pragma unroll
+        for (int i = 0; i < kSmallWaves * 256 / kSmallThreads; ++i)
+            (&s_cnt[0][0])[i * kSmallThreads + threadIdx.x] = 0;
+        __syncthreads(); // counters zeroed, the pairs are in LDS
+        u32 k[IPT], v[IPT], r[IPT];
+#pragma unroll
+        for (int it = 0; it < IPT; ++it) {
+            const u32 idx = seg + it * 64 + lane;
+            const bool valid = idx < n;
+            k[it] = kbuf[idx], v[it] = vbuf[idx];
+            const u32 dg = (k[it] >> shift) & 0xFFu;
+            u64 peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (dg >> b) & 1u;
+                const u64 m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            u32 old = 0;
+            const int leader = valid ? (__ffsll((long long)peers) - 1) : 0;
+            if (valid && lane == leader) {
+                old = s_cnt[wave][dg];
+                s_cnt[wave][dg] = old + (u32)__popcll(peers);
+            }
+            old = __shfl(old, leader, 64);
+            r[it] = old + (u32)__popcll(peers & lt);
+        }
+        __syncthreads(); // every item is in registers, every count is in
+        u32 total = 0, incl = 0;
+        if (threadIdx.x < 256) { // thread = digit: per-wave bases inside the digit, the digit's total, scan over digits
+#pragma unroll
+            for (int w = 0; w < kSmallWaves; ++w) {
+                const u32 c = s_cnt[w][threadIdx.x];
+                s_cnt[w][threadIdx.x] = total;
+                total += c;
+            }
+            incl = total;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 t = __shfl_up(incl, o, 64);
+                if (lane >= o)
+                    incl += t;
+            }
+            if (lane == 63)
+                s_w[wave] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            u32 start = incl - total;
+            for (int w = 0; w < wave; ++w)
+                start += s_w[w];
+#pragma unroll
+            for (int w = 0; w < kSmallWaves; ++w)
+                s_cnt[w][threadIdx.x] += start;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < IPT; ++it) {
+            const u32 idx = seg + it * 64 + lane;
+            if (idx < n) {
+                const u32 pos = s_cnt[wave][(k[it] >> shift) & 0xFFu] + r[it];
+                kbuf[pos] = k[it], vbuf[pos] = v[it];
+            }
+        }
+        __syncthreads(); // the bases in s_cnt are still being read until here: the next pass zeroes them
+    }
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+        const u32 idx = seg + it * 64 + lane;
+        if (idx < n)
+            keys[idx] = kbuf[idx], vals[idx] = vbuf[idx];
+    }
+}
+
+template <int IPT>
+static int launch_sort_small(u32 *keys, u32 *vals, u32 n, int prio, int slot, hipStream_t s)
+{
+    const size_t lds = (size_t)(2 * IPT * kSmallThreads + kSmallWaves * 256 + 4) * sizeof(u32);
+    if (lds > 64 * 1024) {
+        const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(k_sort_small<IPT>), (int)lds, slot);
+        if (rc)
+            return rc;
+    }
+    hipLaunchKernelGGL(k_sort_small<IPT>, dim3(1), dim3(kSmallThreads), lds, s, keys, vals, n, prio);
+    return GWBP_OK;
+}
+
 // isect_offset_encode: offsets[t] = first index whose tile >= t; offsets[n_tiles] = n.
 __global__ __launch_bounds__(256) void k_tile_offsets(const u32 *__restrict__ keys,
                                                       const Counters *__restrict__ ctr, int n_tiles,
@@ -296,7 +410,17 @@ int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *ise
     if (L.n > 0) {
         // level 1: Gaussians by depth (4 passes -> the result is back in buffer 0)
         const int nblk1 = (int)((L.n + kSortItems - 1) / kSortItems);
-        radix_passes(W, W.dkeys, W.dvals, nullptr, (u32)L.n, nblk1, 4, prio, s);
+        int rc1 = GWBP_OK;
+        if (L.n <= 4 * kSmallThreads)
+            rc1 = launch_sort_small<4>(W.dkeys[0], W.dvals[0], (u32)L.n, prio, 11, s);
+        else if (L.n <= 8 * kSmallThreads)
+            rc1 = launch_sort_small<8>(W.dkeys[0], W.dvals[0], (u32)L.n, prio, 12, s);
+        else if (L.n <= kSmallMaxItems)
+            rc1 = launch_sort_small<12>(W.dkeys[0], W.dvals[0], (u32)L.n, prio, 13, s);
+        else
+            radix_passes(W, W.dkeys, W.dvals, nullptr, (u32)L.n, nblk1, 4, prio, s);
+        if (rc1)
+            return rc1;
         // emit intersections front to back
         int rc = launch_emit(L, W, V, W.dvals[0], s);
         if (rc)
