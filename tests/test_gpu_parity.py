@@ -37,9 +37,12 @@ def test_projection_bit_exact(name, orc, dev):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{k} differs bitwise (view {v})"
 
 
-@pytest.mark.parametrize("name", ["T0", "T1", "C1"])
-def test_bin_sort_exact(name, orc, dev):
-    cfg, sc = scene_np(name)
+@pytest.mark.parametrize("name,n_over", [("T0", None), ("T1", None), ("C1", None), ("T1", 5000), ("T1", 9000),
+                                         ("C1", 12288), ("C1", 12289), ("C1", 30000)])
+def test_bin_sort_exact(name, n_over, orc, dev):
+    """n_over: other Gaussian counts on the same geometry -- up to 12288 the depth sort is ONE workgroup (k_sort_small with
+    4, 8 or 12 items per thread), above it the multi-block radix passes."""
+    cfg, sc = scene_np(name, **({"n_gaussians": n_over, "n_views": 1} if n_over else {}))
     d, h = to_dev(sc, dev), npy(sc)
     eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev)
     for v in range(cfg.n_views):
