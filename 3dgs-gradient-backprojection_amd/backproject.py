@@ -135,10 +135,11 @@ class ViewPipeline:
         self.allow_wide = bool(allow_wide)
         # Narrow maps (D <= 16): the front stage stops after the sort, and blend + scatter run as ONE kernel on the caller's
         # stream (gwbp_blend_scatter: no weight store, no scatter kernel); the side stream keeps project + sort of view v+1.
-        # (Large scenes only = two workspaces: on small ones the blend is a latency-bound chain per tile, and keeping it in
-        # the front stage lets three of them run side by side, pipeline_depth().)
-        self.fuse_small = (bool(fuse_small) and scatter_dim is not None and scatter_dim <= Engine.FUSED_MAX_DIM
-                           and len(self.eng) == 2)
+        # On small images the kernel runs a wave per QUARTER tile (four short blend chains per tile instead of one long
+        # one) and takes up to 32 channels; on large ones it needs two workspaces' worth of schedule (len(eng) == 2).
+        small_image = Engine.fused_max_dim(width, height) == Engine.FUSED_MAX_DIM_SMALL
+        self.fuse_small = (bool(fuse_small) and scatter_dim is not None
+                           and scatter_dim <= Engine.fused_max_dim(width, height) and (small_image or len(self.eng) == 2))
         self.front_priority = front_priority  # None: raised wave priority for the front exactly when the wide kernel runs
         self.choose_scatter_kernel(None, None)
         K = len(self.eng)

@@ -450,6 +450,148 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     }
 }
 
+// Small images (<= kQuarterMaxTiles tiles): the fused blend + scatter with ONE QUARTER of a tile per wave, lane = one pixel.
+// A tile's blend is a dependent chain over its Gaussians; with a few hundred tiles the chip holds one wave per SIMD at
+// most and k_blend is bound by that chain's latency (C1: 0.27 ms for 475 waves, then 0.13 ms of scatter kernel).  Four waves
+// per tile run four shorter chains side by side, a pixel's CH channels fit in CH registers (so D <= 32 works), and a
+// contributing (Gaussian, quarter) is flushed by the wave that found it: no store, no scatter kernel.  Same arithmetic
+// per pixel as k_blend, statement for statement (the alpha map is compared bit for bit with the oracle's).
+constexpr int kQuarterMaxTiles = 4096;
+constexpr int kQuarterMaxCh = 32;
+
+template <int CH> // 16 or 32 channels held per pixel (D <= CH)
+__global__ __launch_bounds__(64) void k_blend_scatter_quarter(ViewDev V, const u32 *__restrict__ tile_offsets,
+                                                              const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
+                                                              Counters *__restrict__ ctr, u32 *__restrict__ hdr_count,
+                                                              const u32 *__restrict__ tile_order, float *__restrict__ alphas,
+                                                              int dbg, int prio, float *__restrict__ d_out, float scale_d,
+                                                              FusedArgs fu)
+{
+    front_priority(prio);
+    __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
+    __shared__ float4 s_b[kBatch]; // ca, cb, cc, "may reach this quarter"
+    __shared__ float s_thr[kBatch];
+    const int tile = (int)tile_order[blockIdx.x >> 2]; // longest lists first
+    const int q = (int)(blockIdx.x & 3u);
+    const int tx = tile % V.tile_w, ty = tile / V.tile_w;
+    const int lane = threadIdx.x;
+    const int ix = tx * kTile + (lane & 15), iy = ty * kTile + 4 * q + (lane >> 4);
+    const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
+    const u32 beg = tile_offsets[tile], end = tile_offsets[tile + 1];
+    float T = (ix < V.W && iy < V.H) ? 1.0f : 0.0f, Tout = 1.0f;
+
+    float f[CH];
+    {
+        const float *src = fu.feats + (int64_t)min(iy, V.H - 1) * fu.fs_y + (int64_t)min(ix, V.W - 1) * fu.fs_x;
+        if (fu.vec4) {
+#pragma unroll
+            for (int c4 = 0; c4 < CH / 4; ++c4) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (4 * c4 < fu.D)
+                    v = reinterpret_cast<const float4 *>(src)[c4];
+                f[4 * c4] = v.x, f[4 * c4 + 1] = v.y, f[4 * c4 + 2] = v.z, f[4 * c4 + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                f[c] = c < fu.D ? src[c] : 0.f;
+        }
+    }
+    // flush: lanes 16 g .. 16 g + 15 add channels 16 g + transposed_channel(lane) of F[gid], lane CH adds d[gid]
+    const int my_ch = 16 * (lane >> 4) + transposed_channel(lane);
+    float *const out_base = lane < CH ? fu.F + my_ch : d_out;
+    const size_t out_mul = lane < CH ? (size_t)fu.D : (size_t)1;
+    const float out_scale = lane < CH ? fu.scale_f : scale_d;
+    const bool out_on = lane < CH ? my_ch < fu.D : (lane == CH && d_out != nullptr);
+    u32 npairs = 0, nrec = 0;
+
+    for (u32 batch = beg; batch < end; batch += kBatch) {
+        if (__ballot(T > 0.f) == 0ull)
+            break; // the quarter has terminated
+        const u32 bn = min((u32)kBatch, end - batch);
+        if ((u32)lane < bn) {
+            const u32 gid = vals[batch + lane];
+            const float4 *gp = reinterpret_cast<const float4 *>(g2d + gid);
+            const float4 a = gp[0], b = gp[1];
+            u32 reach = 0; // k_blend's conservative strip mask, this quarter's bit
+            const float L = __logf(255.0f * a.z);
+            if (L > 0.f) {
+                const float idet = 1.0f / (b.x * b.z - b.y * b.y);
+                const float ex = 1.05f * __builtin_sqrtf(2.0f * L * b.z * idet) + 1.0f;
+                const float ey = 1.05f * __builtin_sqrtf(2.0f * L * b.x * idet) + 1.0f;
+                const float x0 = (float)(tx * kTile) + 0.5f, ya = (float)(ty * kTile) + 0.5f + 4.0f * q;
+                const bool xhit = !(a.x + ex < x0 || a.x - ex > x0 + 15.0f);
+                const bool ymiss = (a.y + ey < ya) || (a.y - ey > ya + 3.0f);
+                reach = (xhit && !ymiss) ? 1u : 0u;
+                if (!(ex == ex) || !(ey == ey))
+                    reach = 1u; // degenerate conic: never reject
+            }
+            s_a[lane] = make_float4(a.x, a.y, a.z, __int_as_float((int)gid));
+            s_b[lane] = make_float4(b.x, b.y, b.z, __int_as_float((int)reach));
+            s_thr[lane] = L + 1e-3f;
+        }
+        for (u32 j = 0; j < bn; ++j) {
+            const float4 b = s_b[j];
+            if (uniform((u32)__float_as_int(b.w)) == 0u)
+                continue;
+            const float4 a = s_a[j];
+            const float thr = s_thr[j];
+            const float dx = a.x - px;
+            const float adx = b.x * dx, bdx = b.y * dx;
+            const float dy = a.y - py;
+            const float sigma = __builtin_fmaf(bdx, dy, 0.5f * __builtin_fmaf(adx, dx, (b.z * dy) * dy));
+            if (__ballot(T > 0.f && sigma <= thr) == 0ull)
+                continue;
+            const float alpha = __builtin_fminf(kAlphaMax, a.z * exp_neg_sigma(sigma));
+            const float next_T = T * (1.0f - alpha);
+            const u64 m_ok = __builtin_amdgcn_ballot_w64(sigma >= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin);
+            const u64 m_valid = m_ok & __builtin_amdgcn_ballot_w64(next_T > kTMin);
+            const float T_else = mask_select(m_ok, 0.f, T);
+            const float w = alpha * T;
+            T = mask_select(m_valid, next_T, T_else);
+            Tout = mask_select(m_valid, next_T, Tout);
+            if (m_valid == 0ull)
+                continue;
+            const float wq = mask_select(m_valid, w, 0.f);
+            float p0[16], tot1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                p0[c] = wq * f[c];
+            const float tot0 = transposed_sum16(p0);
+            if constexpr (CH == 32) {
+                float p1[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    p1[c] = wq * f[16 + c];
+                tot1 = transposed_sum16(p1);
+            }
+            float wl = wq;
+            wl += dpp_get<0xB1>(wl);
+            wl += dpp_get<0x4E>(wl);
+            wl += dpp_get<0x141>(wl);
+            wl += dpp_get<0x140>(wl);
+            const float ws = rows_sum(wl);
+            if (!(dbg & 1) && out_on) {
+                const u32 gid = (u32)__float_as_int(a.w);
+                const float val = lane < 16 ? tot0 : (lane < CH ? tot1 : ws);
+                atomicAdd(out_base + (size_t)gid * out_mul, val * out_scale);
+            }
+            npairs += (u32)__popcll(m_valid);
+            ++nrec;
+        }
+    }
+    if (lane == 0) {
+        if (q == 0)
+            hdr_count[tile] = 0u; // the store stays empty
+        if (nrec)
+            atomicAdd(&ctr->n_headers, nrec); // (Gaussian, quarter-tile) flushes here, not (Gaussian, tile) records
+        if (npairs)
+            atomicAdd(&ctr->n_pairs, (u64)npairs);
+    }
+    if (alphas && ix < V.W && iy < V.H)
+        alphas[(size_t)iy * V.W + ix] = 1.0f - Tout;
+}
+
 // Test/debug: expand the weight store into (gid, pix, w) triples.
 __global__ __launch_bounds__(256) void k_dump_pairs(ViewDev V, const u32 *__restrict__ tile_offsets,
                                                     const u32 *__restrict__ hdr_count,
@@ -503,8 +645,9 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
     const bool fused = M != nullptr;
     FusedArgs fu = {};
     if (fused) {
-        if (D < 1 || D > kFusedCh)
-            return set_error(GWBP_EINVAL, "gwbp_blend_scatter: D must be 1..%d (got %d)", kFusedCh, D);
+        const int cap = V.tile_w * V.tile_h <= kQuarterMaxTiles ? kQuarterMaxCh : kFusedCh;
+        if (D < 1 || D > cap)
+            return set_error(GWBP_EINVAL, "gwbp_blend_scatter: D must be 1..%d for this image size (got %d)", cap, D);
         if (M->fs_c != 1 || M->ymap || M->xmap || M->enc)
             return set_error(GWBP_EINVAL, "gwbp_blend_scatter: a full-resolution map with unit channel stride is required");
         if (!M->p || !F)
@@ -524,7 +667,16 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
     hipLaunchKernelGGL(k_blend<H>, dim3(n_tiles), dim3(64), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d,  \
                        W.counters, W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, W.tile_order, alphas,  \
                        W.half[0], W.half[1], W.half_count[0], W.half_count[1], ablate, prio, d, scale_d, fu)
-    if (fused)
+    if (fused && n_tiles <= kQuarterMaxTiles) {
+#define GWBP_QUARTER(C)                                                                                               \
+    hipLaunchKernelGGL(k_blend_scatter_quarter<C>, dim3(4 * n_tiles), dim3(64), 0, s, V, W.tile_offsets, W.vals[fin], W.g2d, \
+                       W.counters, W.hdr_count, W.tile_order, alphas, ablate, prio, d, scale_d, fu)
+        if (D <= 16)
+            GWBP_QUARTER(16);
+        else
+            GWBP_QUARTER(32);
+#undef GWBP_QUARTER
+    } else if (fused)
         GWBP_BLEND(kFused);
     else if (L.flags & GWBP_FLAG_NARROW_SCATTER)
         GWBP_BLEND(kStore);

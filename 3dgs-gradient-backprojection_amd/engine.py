@@ -182,12 +182,21 @@ class Engine:
         self._call("gwbp_blend_weights", *self._args(), C.byref(view), ptr(alphas), self._stream())
         return alphas
 
-    FUSED_MAX_DIM = 16  # gwbp_blend_scatter holds 4 pixels x 16 channels per lane in registers
+    FUSED_MAX_DIM = 16         # gwbp_blend_scatter holds 4 pixels x 16 channels per lane in registers ...
+    FUSED_MAX_DIM_SMALL = 32   # ... or, on images of at most FUSED_SMALL_TILES tiles, one pixel x 32 channels (a wave per
+    FUSED_SMALL_TILES = 4096   # quarter tile: four short blend chains per tile instead of one long one)
+
+    @classmethod
+    def fused_max_dim(cls, width: int, height: int) -> int:
+        tiles = (-(-int(width) // 16)) * (-(-int(height) // 16))
+        return cls.FUSED_MAX_DIM_SMALL if tiles <= cls.FUSED_SMALL_TILES else cls.FUSED_MAX_DIM
 
     @classmethod
     def can_blend_scatter(cls, feats: torch.Tensor) -> bool:
-        """Maps gwbp_blend_scatter takes: [H,W,D] float32, D <= 16, unit channel stride, non-negative strides."""
-        return (feats.dim() == 3 and feats.is_cuda and feats.dtype == torch.float32 and 1 <= feats.shape[2] <= cls.FUSED_MAX_DIM
+        """Maps gwbp_blend_scatter takes: [H,W,D] float32 at full resolution, D <= 16 (<= 32 on small images), unit channel
+        stride, non-negative strides."""
+        return (feats.dim() == 3 and feats.is_cuda and feats.dtype == torch.float32
+                and 1 <= feats.shape[2] <= cls.fused_max_dim(feats.shape[1], feats.shape[0])
                 and feats.stride(2) == 1 and min(feats.stride()) >= 0)
 
     def blend_scatter(self, view, feats, F, d, scale_f=1.0, scale_d=1.0, want_alphas=False):
@@ -196,7 +205,8 @@ class Engine:
         contributing record is reduced across the wave and added to F / d at once.  No weight store is written: the
         view cannot be scattered or rendered again without a new blend_weights()."""
         if not self.can_blend_scatter(feats):
-            raise GwbpError(f"blend_scatter: [H,W,D<={self.FUSED_MAX_DIM}] float32 map with unit channel stride required, "
+            raise GwbpError(f"blend_scatter: [H,W,D] float32 map with unit channel stride and D <= {self.FUSED_MAX_DIM} "
+                            f"(<= {self.FUSED_MAX_DIM_SMALL} on images of at most {self.FUSED_SMALL_TILES} tiles) required, "
                             f"got {tuple(feats.shape)} strides {tuple(feats.stride())}")
         sy, sx, _, D = self._feat_strides(feats, view)
         self._check_acc(F, d, D)

@@ -134,7 +134,7 @@ def main():
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     n_total = args.steps + args.warmup
     # D <= 16: blend + scatter in one kernel (gwbp_blend_scatter), the front stage ends with the sort
-    fused_small = (D <= gsbp_amd.Engine.FUSED_MAX_DIM and not args.no_fuse_small and args.encoder != "fused"
+    fused_small = (D <= gsbp_amd.Engine.fused_max_dim(W, H) and not args.no_fuse_small and args.encoder != "fused"
                    and (args.serial or pipe.fuse_small))
 
     def front(i):
@@ -283,7 +283,8 @@ def main():
                 traffic_source = "profiles/traffic.json (" + str(tj.get("source", "rocprofv3 --pmc, earlier run")) + ")"
             except Exception:
                 traffic = None
-        scatter_kernel = ("k_blend<kFused> (blend + scatter in one kernel, no weight store)" if fused_small else
+        scatter_kernel = (("k_blend_scatter_quarter" if gsbp_amd.Engine.fused_max_dim(W, H) > gsbp_amd.Engine.FUSED_MAX_DIM
+                           else "k_blend<kFused>") + " (blend + scatter in one kernel, no weight store)" if fused_small else
                           "k_scatter_wide" if scatter_choice == "wide" else
                           "k_scatter_full" if (D % 128 == 0 or D <= 64) else "k_scatter")
         out = {

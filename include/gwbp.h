@@ -127,7 +127,8 @@ int gwbp_blend_weights(const gwbp_caps *caps, void *workspace, size_t workspace_
 int gwbp_blend_weights_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                          float *alphas, float scale_d, float *d, void *stream);
 
-/* Blend AND scatter of one view in one kernel, for narrow maps (1 <= D <= 16: backproject_compressed.py:127-165 after its
+/* Blend AND scatter of one view in one kernel, for narrow maps (1 <= D <= 16; on images of at most 4096 tiles, where a wave
+ * takes a quarter tile with one pixel per lane, 1 <= D <= 32: backproject_compressed.py:127-165 after its
  * 512 -> 16 encoder; a 3-channel colour gradient): while a tile is blended its 256 pixels x D channels sit in registers,
  * each contributing (Gaussian, tile) record's sums  F[g, :D] += scale_f * sum_p w f[p, :],  d[g] += scale_d * sum_p w  are
  * reduced across the wave and added with one atomic instruction.  No weight store is written (the workspace's store is
