@@ -320,9 +320,8 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
         eng = engine or Engine(n, width, height, device=dev, tight_binning=True)  # same F and d, shorter tile lists
         for attempt in range(6):  # a capacity overflow invalidates the accumulators: grow the workspace, start over
             if pipeline and len(my_views) > 1:
-                # (bilinear maps are staged by the 128-channel kernel only: no wide kernel, no front priority)
                 depth = pipeline_depth(n, width, height) if pipeline is True else max(2, int(pipeline))
-                pipe = ViewPipeline(n, width, height, dev, scatter_dim=None if upsample == "bilinear" else d_out,
+                pipe = ViewPipeline(n, width, height, dev, scatter_dim=d_out,
                                     allow_wide=allow_wide, fuse_small=fuse_small and not (fuse_encoder and encoder is not None),
                                     engines=[eng] + [Engine(n, width, height, device=dev, tight_binning=eng.tight_binning,
                                                             isect_cap=eng.isect_cap, pair_cap=eng.pair_cap)

@@ -284,7 +284,7 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap
             return rc;
     }
     // fast paths: D % 256 == 0 channel-contiguous (scatter_wide.hip); D % 128 == 0 or D <= 64, any strides (scatter_full.hip)
-    if (D % 256 == 0 && M.fs_c == 1 && !M.bilinear() && !(L.flags & GWBP_FLAG_NARROW_SCATTER)) {
+    if (D % 256 == 0 && M.fs_c == 1 && !(L.flags & GWBP_FLAG_NARROW_SCATTER)) {
         if (d) {
             const int rc = launch_accum_d(L, W, V, scale_d, d, s);
             if (rc)

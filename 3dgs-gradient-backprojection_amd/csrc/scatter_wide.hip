@@ -156,7 +156,31 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     u32 nxt = 0;
     if (phase == 0 && threadIdx.x == 0)
         nxt = atomicAdd(queue, 1u); // claim the next item under the slab loads
-    if (!(dbg & 4) && nh != 0) {
+    if (!(dbg & 4) && nh != 0 && M.bilinear()) {
+        // Bilinear low-resolution map (backproject.py:110-112 folded in): every slab value is the blend of four texels
+        // (L2 / Infinity-Cache resident: the 480 x 480 x 512 map of the lseg script is 472 MB), in ATen's association.
+        // One (pixel, lane) unit per round: 16 dword loads in flight per thread.
+        constexpr int kAll = kHalfPix * 64;
+        constexpr int kUnits = (kAll + kThreads - 1) / kThreads;
+#pragma unroll 1
+        for (int u = 0; u < kUnits; ++u) {
+            const int idx = min(u * kThreads + (int)threadIdx.x, kAll - 1);
+            const int pix = phase * kHalfPix + (idx >> 6);
+            const int ix = min(tx * kTile + (pix & 15), V.W - 1), iy = min(ty * kTile + (pix >> 4), V.H - 1);
+            const int y0 = M.ymap[iy], x0 = M.xmap[ix];
+            const int y1 = min(y0 + 1, M.lr_h - 1), x1 = min(x0 + 1, M.lr_w - 1);
+            const float h1 = M.ly[iy], w1 = M.lx[ix], h0 = 1.0f - h1, w0 = 1.0f - w1;
+            const float *b0 = feats + c0 + lane;
+            const float *pa = b0 + y0 * M.fs_y + x0 * M.fs_x, *pb = b0 + y0 * M.fs_y + x1 * M.fs_x;
+            const float *pc = b0 + y1 * M.fs_y + x0 * M.fs_x, *pd = b0 + y1 * M.fs_y + x1 * M.fs_x;
+            float r[4];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+                r[k4] = h0 * (w0 * pa[64 * k4] + w1 * pb[64 * k4]) + h1 * (w0 * pc[64 * k4] + w1 * pd[64 * k4]);
+            if (kAll % kThreads == 0 || u * kThreads + (int)threadIdx.x < kAll)
+                *reinterpret_cast<float4 *>(lds + (idx >> 6) * kWide + 4 * lane) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    } else if (!(dbg & 4) && nh != 0) {
         // stage 128 px x 256 ch: unit = (pixel, lane) -> 4 coalesced dword loads + one ds_write_b128; 8 units per thread
         constexpr int kAll = kHalfPix * 64;                          // 8192 (pixel, lane) units
         constexpr int kUnits = (kAll + kThreads - 1) / kThreads;     // 8 at 1024 threads

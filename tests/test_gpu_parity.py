@@ -583,12 +583,14 @@ def test_driver_grows_the_workspace_on_overflow(dev, pipeline):
     assert np.abs(da.cpu().numpy() - db.cpu().numpy()).max() <= 1e-5 * float(db.max())
 
 
-def test_create_feature_field_bilinear_matches_materialised(dev):
+@pytest.mark.parametrize("D", [128, 256, 512])
+def test_create_feature_field_bilinear_matches_materialised(D, dev):
     """The driver with upsample="bilinear" (low-resolution maps handed over) against the driver fed with
-    F.interpolate(mode="bilinear", align_corners=False)'s materialised maps (backproject.py:108-113)."""
+    F.interpolate(mode="bilinear", align_corners=False)'s materialised maps (backproject.py:108-113).  D % 256 == 0: the
+    bilinear slab staging of the 256-channel kernel; 128: that of the 128-channel kernel."""
     cfg, sc = scene_np("T1")
     d = to_dev(sc, dev)
-    D, lh, lw = 128, 12, 17
+    lh, lw = 12, 17
     lows = [torch.nn.functional.normalize(torch.randn(lh, lw, D, generator=torch.Generator().manual_seed(40 + v)), dim=2).to(dev)
             for v in range(3)]
 
