@@ -24,7 +24,7 @@ n_fused = 0
 t0 = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
-    n = int(rng.integers(1, 4000))
+    n = int(rng.integers(1, 4000)) if rng.random() < 0.9 else int(rng.integers(4000, 30000))  # (depth-sort variants)
     W, H = int(rng.integers(1, 260)), int(rng.integers(1, 200))
     D = int(rng.choice(DIMS))
     s0 = float(10 ** rng.uniform(-2.6, -0.3))
