@@ -67,21 +67,26 @@ for case in range(n_cases):
     tight = bool(rng.integers(0, 2))
     eng = gsbp_amd.Engine(n, W, H, device=dev, tight_binning=tight, isect_cap=1 << 21, pair_cap=1 << 24)
     eng.set_narrow_scatter(not wide)
-    F = torch.zeros(n, D, device=dev)
-    d = torch.zeros(n, device=dev)
     view = eng.view(vm, K, W, H)
     fused = up is None and bool(rng.integers(0, 2)) and gsbp_amd.Engine.can_blend_scatter(fd)
-    if fused:  # D <= 16, unit channel stride: blend + scatter in one kernel (gwbp_blend_scatter)
-        eng.project(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
-        eng.bin_sort(view)
-        eng.blend_scatter(view, fd, F, d)
-    elif up is None:
-        eng.backproject_view(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev), fd, F, d)
-    else:
-        eng.project(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
-        eng.bin_sort(view)
-        eng.blend_weights(view)
-        eng.scatter(view, fd, F, d, upsample=str(up))
+    for attempt in range(4):  # a capacity overflow invalidates the view: grow the workspace and run it again
+        F = torch.zeros(n, D, device=dev)
+        d = torch.zeros(n, device=dev)
+        if fused:  # D <= 16, unit channel stride: blend + scatter in one kernel (gwbp_blend_scatter)
+            eng.project(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
+            eng.bin_sort(view)
+            eng.blend_scatter(view, fd, F, d)
+        elif up is None:
+            eng.backproject_view(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev), fd, F, d)
+        else:
+            eng.project(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
+            eng.bin_sort(view)
+            eng.blend_weights(view)
+            eng.scatter(view, fd, F, d, upsample=str(up))
+        if not eng.stats()["overflow"]:
+            break
+        eng.grow(eng.stats())
+        eng.set_narrow_scatter(not wide)
     n_fused += int(fused)
     st = eng.stats()
     Fr, dr = np.zeros((n, D), np.float64), np.zeros(n, np.float64)
