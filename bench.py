@@ -142,12 +142,11 @@ def main():
         k = i - args.warmup
         if not args.serial:
             if 0 <= k < args.steps:
-                with torch.cuda.stream(pipe.side):
-                    ev[k][0].record(pipe.side)
+                ev[k][0].record(pipe.stream_of(pipe.i_front))
+            st_front = pipe.stream_of(pipe.i_front)
             pipe.front(views[i], means, quats, scales, opac, d)  # d: added behind the blend when the wide kernel is used
             if 0 <= k < args.steps:
-                with torch.cuda.stream(pipe.side):
-                    ev[k][1].record(pipe.side)
+                ev[k][1].record(st_front)
 
     ahead = {}
 
@@ -212,14 +211,17 @@ def main():
     torch.cuda.synchronize(dev)
     scatter_choice = "narrow"
     if not args.serial:  # the warm-up views' counters pick the scatter kernel (256- or 128-channel) for the timed ones
-        st_w = gsbp_amd.Engine.decode_stats(accum)
+        st_w = pipe.stats()
         scatter_choice = pipe.choose_scatter_kernel(*((st_w["n_pairs"], st_w["n_headers"]) if args.scatter == "auto"
                                                       else (None, None)))
     elif D % 256 == 0 and allow_wide:
         scatter_choice = "wide"  # serial schedule: the faster kernel alone (set before the warm-up), no priority
     F_store.zero_()
     d.zero_()
-    accum.zero_()
+    if pipe is not None:
+        pipe.reset_stats()
+    else:
+        accum.zero_()
 
     def barrier():
         if use_dist:
@@ -247,7 +249,7 @@ def main():
         checked = check_results(args, gsbp_amd, eng, views, (means, quats, scales, opac), pool, encoder, F_rows, d,
                                 row0, use_dist, dist, dev)
 
-    stats = gsbp_amd.Engine.decode_stats(accum)
+    stats = pipe.stats() if pipe is not None else gsbp_amd.Engine.decode_stats(accum)
     tt = torch.tensor([elapsed, float(stats["n_pairs"]), float(stats["overflow"])], dtype=torch.float64, device=dev)
     if use_dist:
         tmax = tt.clone()
@@ -300,8 +302,10 @@ def main():
                        "binning": "alpha-ellipse bounding box (GWBP_FLAG_TIGHT_BINNING)" if tight else "gsplat 3-sigma square",
                        "overflow": overflow, "host_enqueue_ms_per_view": t_enqueue * 1e3 / args.steps,
                        "schedule": "serial" if args.serial else
-                       f"front(v+1..v+{pipe.lookahead}) overlapped with scatter(v): {1 + len(pipe.sides)} streams, "
-                       f"{len(pipe.eng)} workspaces",
+                       (f"{len(pipe.eng)} views in flight, each entirely on a stream of its own ({len(pipe.eng)} workspaces)"
+                        if pipe.independent else
+                        f"front(v+1..v+{pipe.lookahead}) overlapped with scatter(v): {1 + len(pipe.sides)} streams, "
+                        f"{len(pipe.eng)} workspaces"),
                        "stage_ms": {("front(project+sort, side stream, overlapped)" if fused_small else
                                      "front(project+sort+blend, side stream, overlapped)"): t_front,
                                     "blend+scatter" if fused_small else "scatter": t_scatter}},
