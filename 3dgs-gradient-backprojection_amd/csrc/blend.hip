@@ -432,6 +432,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         }
     }
     if (lane == 0) {
+        if (MODE == kFused && blockIdx.x == 0)
+            ctr->blend_kind = kBlendFused; // (no k_pool_stats launch behind the fused kernel: the pool is untouched)
         hdr_count[tile] = MODE == kFused ? 0u : hdr_n; // kFused: the store stays empty
         if constexpr (HALVES)
             half_cnt_a[tile] = n_top, half_cnt_b[tile] = n_bot;
@@ -581,6 +583,8 @@ __global__ __launch_bounds__(64) void k_blend_scatter_quarter(ViewDev V, const u
         }
     }
     if (lane == 0) {
+        if (blockIdx.x == 0)
+            ctr->blend_kind = kBlendFused; // (no k_pool_stats launch behind the fused kernels: the pool is untouched)
         if (q == 0)
             hdr_count[tile] = 0u; // the store stays empty
         if (nrec)
@@ -683,8 +687,9 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
     else
         GWBP_BLEND(kHalves);
 #undef GWBP_BLEND
-    hipLaunchKernelGGL(k_pool_stats, dim3(1), dim3(1), 0, s, W.shards, W.counters,
-                       fused ? kBlendFused : (L.flags & GWBP_FLAG_NARROW_SCATTER) ? 0u : kBlendHalves);
+    if (!fused)
+        hipLaunchKernelGGL(k_pool_stats, dim3(1), dim3(1), 0, s, W.shards, W.counters,
+                           (L.flags & GWBP_FLAG_NARROW_SCATTER) ? 0u : kBlendHalves);
     return check_hip(hipGetLastError(), "blend launch");
 }
 
