@@ -148,6 +148,7 @@ int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *
                    const float *scales, const float *opac, int32_t *radii, float *means2d, float *depths,
                    float *conics, hipStream_t s);
 int launch_emit(const Layout &L, const Ws &W, const ViewDev &V, const u32 *order, hipStream_t s);
+int launch_emit_scanned(const Layout &L, const Ws &W, const ViewDev &V, const u32 *order, hipStream_t s);
 int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *isect_ids, int32_t *flatten_ids,
                     int32_t *tile_offsets, hipStream_t s);
 struct FeatMap;

@@ -312,6 +312,15 @@ int launch_emit(const Layout &L, const Ws &W, const ViewDev &V, const u32 *order
     return check_hip(hipGetLastError(), "emit launch");
 }
 
+// k_emit alone: blocksums and Counters::n_isect are already in place (k_sort_small's tail)
+int launch_emit_scanned(const Layout &L, const Ws &W, const ViewDev &V, const u32 *order, hipStream_t s)
+{
+    const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
+    hipLaunchKernelGGL(k_emit, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, V.tile_w, order, W.rect, W.touched,
+                       W.blocksums, W.counters, W.keys[0], W.vals[0], prio);
+    return check_hip(hipGetLastError(), "emit launch");
+}
+
 int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *means, const float *quats,
                    const float *scales, const float *opac, int32_t *radii, float *means2d, float *depths,
                    float *conics, hipStream_t s)

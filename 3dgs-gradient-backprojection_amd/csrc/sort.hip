@@ -186,8 +186,21 @@ constexpr int kSmallThreads = 1024;
 constexpr int kSmallWaves = kSmallThreads / 64;
 constexpr int kSmallMaxItems = 12 * kSmallThreads; // 12 items per thread: 103 VGPRs (16: 128 + spills)
 
+// The tail also does the scan in front of the emit (k_sorted_blocksums + k_scan_blocksums of project.hip: two more launches):
+// after the last pass a thread's items are positions of the depth order, the tiles they touch are prefix-summed in that
+// order (wave scan per item slot, carried over the slots, then over the waves), the exclusive sums at every 256th position
+// are what k_emit expects as block offsets, and the total becomes Counters::n_isect (or the overflow flag).  (Emitting
+// from here as well was measured: one workgroup writes the 92 K pairs of a C1 view in 90 us, k_emit's 40 blocks in 6.)
+struct SmallEmit {
+    const u32 *touched; // tiles per Gaussian
+    u32 *blocksums;     // exclusive prefix of `touched` in depth order at positions 0, 256, 512, ...
+    Counters *ctr;
+    u32 isect_cap;
+};
+
 template <int IPT> // items per thread: N <= IPT * 1024
-__global__ __launch_bounds__(kSmallThreads) void k_sort_small(u32 *__restrict__ keys, u32 *__restrict__ vals, u32 n, int prio)
+__global__ __launch_bounds__(kSmallThreads) void k_sort_small(u32 *__restrict__ keys, u32 *__restrict__ vals, u32 n, int prio,
+                                                              SmallEmit em)
 {
     front_priority(prio);
     extern __shared__ u32 s_small[];
@@ -270,16 +283,59 @@ __global__ __launch_bounds__(kSmallThreads) void k_sort_small(u32 *__restrict__ 
         }
         __syncthreads(); // the bases in s_cnt are still being read until here: the next pass zeroes them
     }
+    u32 pos[IPT];
+    u32 running = 0; // tiles touched by this wave's earlier item slots
 #pragma unroll
     for (int it = 0; it < IPT; ++it) {
         const u32 idx = seg + it * 64 + lane;
-        if (idx < n)
-            keys[idx] = kbuf[idx], vals[idx] = vbuf[idx];
+        const bool valid = idx < n;
+        const u32 gid = valid ? vbuf[idx] : 0u;
+        if (valid)
+            keys[idx] = kbuf[idx], vals[idx] = gid;
+        const u32 cnt = valid ? em.touched[gid] : 0u;
+        u32 incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(incl, o, 64);
+            if (lane >= o)
+                incl += t;
+        }
+        pos[it] = running + incl - cnt;
+        running += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    __syncthreads(); // s_cnt is free again: its first row carries the wave totals
+    u32 *s_tot = &s_cnt[0][0];
+    if (lane == 0)
+        s_tot[wave] = running;
+    __syncthreads();
+    u32 woff = 0;
+    u64 total = 0; // 64 bits: a wrapped 32-bit sum must not pass the capacity check
+#pragma unroll
+    for (int w = 0; w < kSmallWaves; ++w) {
+        const u32 t = s_tot[w];
+        woff += w < wave ? t : 0u;
+        total += t;
+    }
+    if (threadIdx.x == 0) {
+        if (total > (u64)em.isect_cap) {
+            atomicOr(&em.ctr->overflow, 1u);
+            em.ctr->n_isect = 0; // downstream stages see an empty view; caller must retry with larger caps
+        } else {
+            em.ctr->n_isect = (u32)total;
+        }
+    }
+    if ((lane & 63) == 0) { // idx = seg + 64 it is a multiple of 256 for every fourth item slot of lane 0
+#pragma unroll
+        for (int it = 0; it < IPT; ++it) {
+            const u32 idx = seg + it * 64;
+            if ((idx & (u32)(kScanBlock - 1)) == 0u && idx < n)
+                em.blocksums[idx / (u32)kScanBlock] = woff + pos[it];
+        }
     }
 }
 
 template <int IPT>
-static int launch_sort_small(u32 *keys, u32 *vals, u32 n, int prio, int slot, hipStream_t s)
+static int launch_sort_small(u32 *keys, u32 *vals, u32 n, int prio, int slot, const SmallEmit &em, hipStream_t s)
 {
     const size_t lds = (size_t)(2 * IPT * kSmallThreads + kSmallWaves * 256 + 4) * sizeof(u32);
     if (lds > 64 * 1024) {
@@ -287,7 +343,7 @@ static int launch_sort_small(u32 *keys, u32 *vals, u32 n, int prio, int slot, hi
         if (rc)
             return rc;
     }
-    hipLaunchKernelGGL(k_sort_small<IPT>, dim3(1), dim3(kSmallThreads), lds, s, keys, vals, n, prio);
+    hipLaunchKernelGGL(k_sort_small<IPT>, dim3(1), dim3(kSmallThreads), lds, s, keys, vals, n, prio, em);
     return GWBP_OK;
 }
 
@@ -410,21 +466,24 @@ int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *ise
     if (L.n > 0) {
         // level 1: Gaussians by depth (4 passes -> the result is back in buffer 0)
         const int nblk1 = (int)((L.n + kSortItems - 1) / kSortItems);
-        int rc1 = GWBP_OK;
-        if (L.n <= 4 * kSmallThreads)
-            rc1 = launch_sort_small<4>(W.dkeys[0], W.dvals[0], (u32)L.n, prio, 11, s);
-        else if (L.n <= 8 * kSmallThreads)
-            rc1 = launch_sort_small<8>(W.dkeys[0], W.dvals[0], (u32)L.n, prio, 12, s);
-        else if (L.n <= kSmallMaxItems)
-            rc1 = launch_sort_small<12>(W.dkeys[0], W.dvals[0], (u32)L.n, prio, 13, s);
-        else
+        if (L.n <= kSmallMaxItems) { // small scene: depth sort and the emit's scan in one single-workgroup launch
+            const SmallEmit em = {W.touched, W.blocksums, W.counters, (u32)L.isect_cap};
+            int rc1;
+            if (L.n <= 4 * kSmallThreads)
+                rc1 = launch_sort_small<4>(W.dkeys[0], W.dvals[0], (u32)L.n, prio, 11, em, s);
+            else if (L.n <= 8 * kSmallThreads)
+                rc1 = launch_sort_small<8>(W.dkeys[0], W.dvals[0], (u32)L.n, prio, 12, em, s);
+            else
+                rc1 = launch_sort_small<12>(W.dkeys[0], W.dvals[0], (u32)L.n, prio, 13, em, s);
+            if (rc1 || (rc1 = launch_emit_scanned(L, W, V, W.dvals[0], s)))
+                return rc1;
+        } else {
             radix_passes(W, W.dkeys, W.dvals, nullptr, (u32)L.n, nblk1, 4, prio, s);
-        if (rc1)
-            return rc1;
-        // emit intersections front to back
-        int rc = launch_emit(L, W, V, W.dvals[0], s);
-        if (rc)
-            return rc;
+            // emit intersections front to back
+            const int rc = launch_emit(L, W, V, W.dvals[0], s);
+            if (rc)
+                return rc;
+        }
     }
     // level 2: intersections by tile id
     const int passes = sort_passes(n_tiles);
