@@ -158,6 +158,10 @@ class ViewPipeline:
         # counters: one accumulator per stream that adds to it (k_accum_stats is a plain read-modify-write)
         self.accums = [torch.zeros(32, dtype=torch.uint8, device=self.dev) for _ in range(K if self.independent else 1)]
         self.accum = self.accums[0]
+        if self.independent:  # the host is the limit on such scenes: no stream context switch per call either
+            for e, st in zip(self.eng, self.sides):
+                e.bind_stream(st)
+            self.ev_ready = [torch.cuda.Event() for _ in range(K)]
         self.i_front = 0    # views whose front stage has been enqueued
         self.i_scatter = 0  # views whose scatter stage has been enqueued
         self.pending = {}
@@ -196,6 +200,13 @@ class ViewPipeline:
         elif not self.independent:
             side.wait_event(self.ev_done[b])  # workspace b is free once scatter(i-K) has finished
         # (independent: scatter(i-K) was enqueued on this very stream)
+        if self.independent:  # the engine is bound to `side`
+            e = self.eng[b]
+            e.project(view, means, quats, scales, opacities)
+            e.bin_sort(view)
+            self.pending[self.i_front] = (view, False, False)
+            self.i_front += 1
+            return
         with torch.cuda.stream(side):
             e = self.eng[b]
             e.project(view, means, quats, scales, opacities)
@@ -203,8 +214,7 @@ class ViewPipeline:
             d_done = d is not None and self.wide and not self.fuse_small
             if not self.fuse_small:
                 e.blend_weights(view, d=d if d_done else None, scale_d=scale_d)
-            if not self.independent:
-                self.ev_front[b].record(side)
+            self.ev_front[b].record(side)
         self.pending[self.i_front] = (view, d_done, not self.fuse_small)
         self.i_front += 1
 
@@ -244,14 +254,13 @@ class ViewPipeline:
         if self.independent:
             # on the view's own stream, behind its front; the map was produced on the caller's stream
             side = self.sides[b]
-            ready = torch.cuda.Event()
+            ready = self.ev_ready[b]  # (its previous use, view i - K, was waited for on this same stream long ago)
             ready.record(main)
             side.wait_event(ready)
             if after is not None:
                 side.wait_event(after)
             feats.record_stream(side)
-            with torch.cuda.stream(side):
-                self._scatter_on(side, b, feats, F, d, scale_f, scale_d, t0, t1, upsample, encoder)
+            self._scatter_on(side, b, feats, F, d, scale_f, scale_d, t0, t1, upsample, encoder)  # engine bound to `side`
             self.i_scatter += 1
             return
         if after is not None:
@@ -290,6 +299,14 @@ class ViewPipeline:
         main = torch.cuda.current_stream(self.dev)
         for side in self.sides:
             main.wait_stream(side)
+
+    def release(self):
+        """End of the job: the caller's stream waits for everything enqueued, and engines that were bound to a stream of
+        this pipeline follow torch's current stream again (an engine handed in by the caller outlives the pipeline)."""
+        self.join()
+        if self.independent:
+            for e in self.eng:
+                e.bind_stream(None)
 
     def reset_stats(self):
         self.join()
@@ -408,6 +425,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                         feats, after = feature_fn(v), None
                     pipe.scatter(feats, F, d, sf, sd, upsample=upsample, after=after)
                 stats = pipe.stats()
+                pipe.release()
             else:
                 accum = torch.zeros(32, dtype=torch.uint8, device=dev)
                 for i, v in enumerate(my_views):

@@ -73,6 +73,7 @@ class Engine:
         # because meta["isect_ids"] of the drop-in operator must show gsplat's 3-sigma binning
         self.tight_binning = bool(tight_binning)
         self._halves = False  # the workspace holds the half-tile lists + weight sums of the view blended last
+        self.stream, self._stream_handle = None, None
         self._alloc()
 
     def set_front_priority(self, on: bool) -> None:
@@ -116,7 +117,15 @@ class Engine:
 
     # ---- helpers -----------------------------------------------------------------------------------------
     def _stream(self):
+        if self.stream is not None:  # bound by a driver that keeps this engine on one stream (no context switch per call)
+            return self._stream_handle
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def bind_stream(self, stream: Optional[torch.cuda.Stream]):
+        """Launch this engine's kernels on `stream` whatever torch's current stream is (None: follow the current stream).
+        Methods that allocate outputs (want_alphas, render, ...) still allocate on the current stream."""
+        self.stream = stream
+        self._stream_handle = C.c_void_p(stream.cuda_stream) if stream is not None else None
 
     def _call(self, name: str, *args):
         """One C-ABI call with this engine's device current: libgwbp launches on the CURRENT HIP device, while the

@@ -243,6 +243,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    if pipe is not None:
+        pipe.release()  # (the result check below drives the first engine on the default stream)
     checked = None
     if not args.no_check:
         # (d itself holds the all-reduced denominators of ALL Gaussians; d_sum is this rank's row block of it)
