@@ -244,22 +244,27 @@ class ViewPipeline:
         out.record_stream(main)
         return out, done
 
-    def scatter(self, feats, F, d, scale_f=1.0, scale_d=1.0, t0=None, t1=None, upsample=None, after=None, encoder=None):
+    def scatter(self, feats, F, d, scale_f=1.0, scale_d=1.0, t0=None, t1=None, upsample=None, after=None, encoder=None,
+                ready: bool = False):
         """t0/t1: optional timing events recorded right around the scatter launch (after the cross-stream waits).
         after: an event the feature map depends on (encode_ahead).
-        encoder: scatter feats @ encoder with the encoder fused into the slab staging (Engine.scatter_encoded)."""
+        encoder: scatter feats @ encoder with the encoder fused into the slab staging (Engine.scatter_encoded).
+        ready: the map needs no cross-stream wait -- it was produced on scatter_stream() (a feature function run under
+        `with torch.cuda.stream(pipe.scatter_stream())`) or is known to be complete (a pool built before the job); only
+        looked at by the view-per-stream schedule, where that wait is a third of the host's time per view."""
         i = self.i_scatter
         b = i % len(self.eng)
         main = torch.cuda.current_stream(self.dev)
         if self.independent:
             # on the view's own stream, behind its front; the map was produced on the caller's stream
             side = self.sides[b]
-            ready = self.ev_ready[b]  # (its previous use, view i - K, was waited for on this same stream long ago)
-            ready.record(main)
-            side.wait_event(ready)
+            if not ready:
+                ev = self.ev_ready[b]  # (its previous use, view i - K, was waited for on this same stream long ago)
+                ev.record(main)
+                side.wait_event(ev)
+                feats.record_stream(side)
             if after is not None:
                 side.wait_event(after)
-            feats.record_stream(side)
             self._scatter_on(side, b, feats, F, d, scale_f, scale_d, t0, t1, upsample, encoder)  # engine bound to `side`
             self.i_scatter += 1
             return
@@ -289,6 +294,12 @@ class ViewPipeline:
         if t1 is not None:
             t1.record(main)
         e.accumulate_stats(self.accums[b if self.independent else 0])
+
+    def scatter_stream(self) -> torch.cuda.Stream:
+        """The stream the NEXT scatter() runs on (the caller's current stream unless a view runs on a stream of its own)."""
+        if self.independent:
+            return self.sides[self.i_scatter % len(self.eng)]
+        return torch.cuda.current_stream(self.dev)
 
     def stream_of(self, i: int) -> torch.cuda.Stream:
         """The stream view i's FRONT stage runs on (timing events of a driver)."""
@@ -422,8 +433,10 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                         if i + 1 < len(my_views):
                             ahead = pipe.encode_ahead(feature_fn(my_views[i + 1]), encoder)
                     else:
-                        feats, after = feature_fn(v), None
-                    pipe.scatter(feats, F, d, sf, sd, upsample=upsample, after=after)
+                        # (view-per-stream schedule: the feature function runs on the stream that consumes its map)
+                        with torch.cuda.stream(pipe.scatter_stream()):
+                            feats, after = feature_fn(v), None
+                    pipe.scatter(feats, F, d, sf, sd, upsample=upsample, after=after, ready=encoder is None)
                 stats = pipe.stats()
                 pipe.release()
             else:

@@ -189,8 +189,9 @@ def main():
                 ev[k][3].record()
             return
         timed = 0 <= k < args.steps
+        # ready: the maps come from a pool built (and synchronised) before the timed region
         pipe.scatter(feats, F, d, t0=ev[k][2] if timed else None, t1=ev[k][3] if timed else None, after=after,
-                     encoder=fenc)
+                     encoder=fenc, ready=encoder is None)
 
     def run_views(lo, hi):
         """Views lo..hi-1 through the two-deep pipeline; every front and every scatter of the range is enqueued here."""
