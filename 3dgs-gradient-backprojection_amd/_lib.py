@@ -103,12 +103,17 @@ _lib: Optional[C.CDLL] = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        path = os.environ.get("GWBP_LIB", LIB_PATH)  # GWBP_LIB: developer knob for A/B / PROFILE builds of the same ABI
+        path = os.environ.get("GWBP_LIB", LIB_PATH)  # GWBP_LIB: developer knob for A/B builds of the same ABI (PROFILE builds
+        # additionally need GWBP_ALLOW_PROFILE=1, see below)
         if not os.path.exists(path):
             raise GwbpError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU or PyTorch fallback for this path)")
         L = C.CDLL(path)
         L.gwbp_version.restype = C.c_char_p
+        if b"PROFILE" in L.gwbp_version() and os.environ.get("GWBP_ALLOW_PROFILE") != "1":
+            # a PROFILE build reads ablation knobs from the environment and may produce invalid results: never by accident
+            raise GwbpError(f"{path} is a PROFILE build ({L.gwbp_version().decode()}); it is only loaded with "
+                            "GWBP_ALLOW_PROFILE=1 (tools/ablate_scatter.sh, tools/stamp_scatter.py)")
         L.gwbp_last_error_string.restype = C.c_char_p
         for name in EXPORTS[2:]:
             if path != LIB_PATH and not hasattr(L, name):

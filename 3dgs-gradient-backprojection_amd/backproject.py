@@ -237,7 +237,9 @@ class ViewPipeline:
             # one workgroup per CU: streaming harder doubles the memory latency of the front stage and the scatter beside it
             n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
             per_cu = self.ENCODER_WORKGROUPS_PER_CU or (2.0 if self.fuse_small else 1.0)
-            out = self.eng[0].encode_map(feats, encoder, workgroups=max(1, int(per_cu * n_cu)))
+            # stream=: in the view-per-stream schedule eng[0] is BOUND to sides[0]; the encoder must run here, behind
+            # `ready`, and `done` must cover it
+            out = self.eng[0].encode_map(feats, encoder, workgroups=max(1, int(per_cu * n_cu)), stream=self.enc_stream)
             done = torch.cuda.Event()
             done.record(self.enc_stream)
         feats.record_stream(self.enc_stream)
@@ -349,7 +351,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                          views: Optional[Sequence[int]] = None, view_fn=None, pipeline: bool = True,
                          return_partials: bool = False, verbose: bool = False, upsample: Optional[str] = None,
                          gather: bool = True, allow_wide: bool = True, fuse_encoder: bool = False,
-                         fuse_small: bool = True):
+                         fuse_small: bool = True, feature_fn_stream_safe: bool = False):
     """Build the [N, dim_out] per-Gaussian feature field.
 
     means/quats/scales/opacities: post-activation Gaussians (backproject.py:55-57), device tensors.
@@ -369,6 +371,13 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     kernel one view ahead on a third stream (gwbp_encode_map).
     fuse_small: maps of at most 16 channels (after the encoder) are blended AND scattered by one kernel
     (gwbp_blend_scatter: no weight store, no scatter kernel; C5 1.96 -> 1.42 ms/view); False keeps the two-kernel form.
+    feature_fn_stream_safe: STREAM CONTRACT of feature_fn.  False (default): feature_fn runs on the caller's current stream
+    and every map is handed to its consumer stream with an event -- any feature function is safe, including one that
+    returns a prefetched tensor, reuses a static output buffer or replays a graph (the buffer must still not be overwritten
+    before the view that reads it has been scattered: `pipeline` views may be in flight).  True: in the view-per-stream
+    schedule (small scenes, <= 32-channel maps) feature_fn is called under `torch.cuda.stream(<the consuming stream>)` and
+    no event is recorded (a third of the host time per view there); only for functions that allocate and produce their
+    output entirely on torch's current stream at call time.
     pipeline: overlap the front stages of the next view(s) with the scatter of view v (ViewPipeline); True = depth chosen by
     pipeline_depth(N, width, height), an int >= 2 = that many workspaces, False = one stream.
     gather: under a process group, all-gather the finalised row blocks so that every rank returns the whole [N, dim_out]
@@ -432,11 +441,14 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                         feats, after = ahead
                         if i + 1 < len(my_views):
                             ahead = pipe.encode_ahead(feature_fn(my_views[i + 1]), encoder)
-                    else:
+                    elif feature_fn_stream_safe:
                         # (view-per-stream schedule: the feature function runs on the stream that consumes its map)
                         with torch.cuda.stream(pipe.scatter_stream()):
                             feats, after = feature_fn(v), None
-                    pipe.scatter(feats, F, d, sf, sd, upsample=upsample, after=after, ready=encoder is None)
+                    else:
+                        feats, after = feature_fn(v), None  # on the caller's stream; scatter() waits for it with an event
+                    pipe.scatter(feats, F, d, sf, sd, upsample=upsample, after=after,
+                                 ready=encoder is None and feature_fn_stream_safe)
                 stats = pipe.stats()
                 pipe.release()
             else:

@@ -223,9 +223,9 @@ extern "C" {
 const char *gwbp_version(void)
 {
 #ifdef GWBP_PROFILE
-    return "libgwbp gfx950 r2 (PROFILE build: ablation knobs live, results may be invalid)";
+    return "libgwbp gfx950 r3 (PROFILE build: ablation knobs live, results may be invalid)";
 #else
-    return "libgwbp gfx950 r2";
+    return "libgwbp gfx950 r3";
 #endif
 }
 const char *gwbp_last_error_string(void) { return g_err; }

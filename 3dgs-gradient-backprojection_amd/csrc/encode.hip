@@ -88,7 +88,9 @@ int launch_encode_map(const float *feats, int64_t fs_y, int64_t fs_x, int H, int
 {
     const size_t lds = (size_t)K * kEncN * sizeof(float);
     if (lds > 64 * 1024) {
-        const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(k_encode_map), (int)lds, 6);
+        // ensure_dynamic_lds remembers "raised" per (device, slot), not the size: always raise to the largest request this
+        // entry point accepts (K = 2048), or a K = 1040 call followed by K = 2048 would launch over the limit
+        const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(k_encode_map), 2048 * kEncN * (int)sizeof(float), 6);
         if (rc)
             return rc;
     }

@@ -377,24 +377,43 @@ class Engine:
                                              C.c_int64(sc), D, C.c_float(scale_f), C.c_float(scale_d), ptr(F),
                                              ptr(d), self._stream())
 
-    def encode_map(self, feats: torch.Tensor, encoder: torch.Tensor, workgroups: int = 0) -> torch.Tensor:
-        """feats[H,W,K] @ encoder[K,n] (backproject_compressed.py:127) -> [H,W,n].  The hand-written skinny GEMM
-        (gwbp_encode_map: the map is read once at HBM rate, exact fp32 MFMA) when the shape allows -- n <= 16, K % 16 == 0,
-        channel-contiguous 16-B aligned pixels -- otherwise the library GEMM behind torch.matmul.  workgroups: 0 = fastest
-        alone; one per CU when the call overlaps latency-bound kernels on other streams (ViewPipeline.encode_ahead)."""
+    @staticmethod
+    def can_encode_map(feats: torch.Tensor, encoder: torch.Tensor) -> bool:
+        """Shapes gwbp_encode_map takes: [H,W,K] float32 with channel-contiguous 16-B aligned pixels, K % 16 == 0, K <= 2048,
+        at most 16 outputs (the reference's encoder is 512 -> 16, backproject_compressed.py:26,127)."""
+        if feats.dim() != 3 or encoder.dim() != 2 or feats.shape[2] != encoder.shape[0]:
+            return False
+        sy, sx, sc = feats.stride()
+        K, n = encoder.shape
+        return (feats.is_cuda and feats.dtype == torch.float32 and encoder.dtype == torch.float32 and n <= 16 and
+                K % 16 == 0 and K <= 2048 and sc == 1 and sy % 4 == 0 and sx % 4 == 0 and feats.data_ptr() % 16 == 0
+                and sy >= 0 and sx >= 0)
+
+    def encode_map(self, feats: torch.Tensor, encoder: torch.Tensor, workgroups: int = 0,
+                   stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+        """feats[H,W,K] @ encoder[K,n] (backproject_compressed.py:127) -> [H,W,n] with the hand-written skinny GEMM
+        (gwbp_encode_map: the map is read once at HBM rate, exact fp32 MFMA).  Shapes it does not take (can_encode_map)
+        RAISE: the hot stage never falls back to a library GEMM silently -- callers that want one write `feats @ encoder`.
+        workgroups: 0 = fastest alone; one per CU when the call overlaps latency-bound kernels on other streams
+        (ViewPipeline.encode_ahead).  stream: launch there instead of on this engine's stream (an engine bound to a view's
+        stream by bind_stream must not run another view's encoder on it); the output is allocated under that stream."""
         if feats.dim() != 3 or encoder.dim() != 2 or feats.shape[2] != encoder.shape[0]:
             raise GwbpError(f"encode_map: [H,W,K] @ [K,n] expected, got {tuple(feats.shape)} @ {tuple(encoder.shape)}")
+        if not self.can_encode_map(feats, encoder):
+            raise GwbpError("encode_map: [H,W,K] float32 channel-contiguous 16-B aligned map, K % 16 == 0, K <= 2048, "
+                            f"<= 16 outputs required, got {tuple(feats.shape)} strides {tuple(feats.stride())} @ "
+                            f"{tuple(encoder.shape)} (use feats @ encoder for other shapes)")
         H, W, K = feats.shape
         n = encoder.shape[1]
-        sy, sx, sc = feats.stride()
-        ok = (feats.is_cuda and feats.dtype == torch.float32 and encoder.dtype == torch.float32 and n <= 16 and
-              K % 16 == 0 and K <= 2048 and sc == 1 and sy % 4 == 0 and sx % 4 == 0 and feats.data_ptr() % 16 == 0
-              and sy >= 0 and sx >= 0)
-        if not ok:
-            return feats @ encoder
+        sy, sx, _ = feats.stride()
         enc = encoder.contiguous()
-        out = torch.empty(H, W, n, device=feats.device, dtype=torch.float32)
-        self._call("gwbp_encode_map", ptr(feats), sy, sx, H, W, K, ptr(enc), n, ptr(out), int(workgroups), self._stream())
+        handle = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        if stream is None:
+            out = torch.empty(H, W, n, device=feats.device, dtype=torch.float32)
+        else:
+            with torch.cuda.stream(stream):
+                out = torch.empty(H, W, n, device=feats.device, dtype=torch.float32)
+        self._call("gwbp_encode_map", ptr(feats), sy, sx, H, W, K, ptr(enc), n, ptr(out), int(workgroups), handle)
         return out
 
     def finalize(self, F, d, out=None):

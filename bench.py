@@ -25,8 +25,6 @@ sys.path.insert(0, ROOT)
 # ViewPipeline.  Must be set before the HIP runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -59,15 +57,24 @@ def main():
                     help="gsplat's 3-sigma tile binning instead of GWBP_FLAG_TIGHT_BINNING (same F and d either way)")
     ap.add_argument("--no-fuse-small", action="store_true",
                     help="D <= 16: keep blend (weight store) and scatter as two kernels instead of gwbp_blend_scatter")
+    ap.add_argument("--total-views", type=int, default=0,
+                    help="STRONG scaling (BASELINE.json configs[2]): the same T views sharded r, r+R, ... over the ranks; "
+                         "overrides --steps (each rank times its ceil/floor(T / world) views)")
     ap.add_argument("--serial", action="store_true", help="one stream, no overlap of front(v+1) with scatter(v)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start N FRESH rank processes (one per GPU) under torch.distributed.run and
+        # relay rank 0's JSON line.  Nothing in THIS process has touched the GPU (argparse only), and it never re-execs.
+        raise SystemExit(self_launch(args.gpus))
+    global torch
+    import torch  # (after the self-launch decision: the launching parent imports nothing that could start the HIP runtime)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         "(python bench.py --gpus N launches them itself)")
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -94,8 +101,22 @@ def main():
     D_in = cfg.feat_dim
     means, quats, scales, opac = [t.to(dev) for t in syn.activate(syn.make_scene(cfg))]
     K = syn.intrinsics(cfg)
-    n_views_needed = world * (args.steps + args.warmup)
-    vms = syn.make_cameras(cfg, n_views=max(cfg.n_views, n_views_needed))
+    strong = args.total_views > 0
+    if strong:  # the same T views whatever the world size; warm-up views are extra cameras behind them
+        timed_ids = syn.view_shard(args.total_views, rank, world)
+        args.steps = len(timed_ids)
+        if args.steps == 0:
+            raise SystemExit("--total-views must be at least the number of ranks")
+        my_views = [args.total_views + rank + world * i for i in range(args.warmup)] + timed_ids
+        n_views_needed = args.total_views + world * args.warmup
+    else:
+        my_views = [rank + world * i for i in range(args.steps + args.warmup)]
+        n_views_needed = world * (args.steps + args.warmup)
+    if strong:  # the timed cameras must not depend on the world size: warm-up cameras come from a seed of their own
+        vms = torch.cat([syn.make_cameras(cfg, n_views=max(cfg.n_views, args.total_views))[:args.total_views],
+                         syn.make_cameras(cfg, seed=syn.CAMERA_SEED + 1, n_views=max(1, world * args.warmup))])
+    else:
+        vms = syn.make_cameras(cfg, n_views=max(cfg.n_views, n_views_needed))
     encoder = syn.make_encoder(cfg).to(dev) if cfg.encoder_dim else None
     D = cfg.encoder_dim or D_in
 
@@ -104,7 +125,6 @@ def main():
     tight = not args.exact_binning
     eng = gsbp_amd.Engine(N, W, H, device=dev, tight_binning=tight)
     F, d, F_store = gsbp_amd.backproject.alloc_accumulators(N, D, dev, world)
-    my_views = [rank + world * i for i in range(args.steps + args.warmup)]
     views = [eng.view(vms[v], K, W, H) for v in my_views]
 
     # capacity check on one untimed view (the timed loop never reads sizes back)
@@ -237,12 +257,19 @@ def main():
     run_views(args.warmup, n_total)  # the whole of every timed view, its front stage included, lies in the region
     t_enqueue = time.perf_counter() - t0  # host time to enqueue the timed views (small scenes: is the host the limit?)
     F_rows, d_sum, row0 = F, d, 0
+    ex = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     if use_dist:
         # the path's one exchange step, inside the timed region: reduce-scatter of F (rank r keeps the rows it would
-        # finalise), all-reduce of d
+        # finalise), all-reduce of d.  The collectives are enqueued on the caller's stream: it must first wait for the
+        # side streams (view-per-stream schedule: the last views' atomics are still in flight there).
+        if pipe is not None:
+            pipe.join()
+        ex[0].record()
         F_rows, d_sum, row0 = gsbp_amd.reduce_partials_sharded(F, d, F_store)
+        ex[1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    exchange_ms = ex[0].elapsed_time(ex[1]) if use_dist else 0.0
 
     if pipe is not None:
         pipe.release()  # (the result check below drives the first engine on the default stream)
@@ -253,15 +280,28 @@ def main():
                                 row0, use_dist, dist, dev)
 
     stats = pipe.stats() if pipe is not None else gsbp_amd.Engine.decode_stats(accum)
-    tt = torch.tensor([elapsed, float(stats["n_pairs"]), float(stats["overflow"])], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed, float(stats["n_pairs"]), float(stats["overflow"]), exchange_ms, float(args.steps)],
+                      dtype=torch.float64, device=dev)
+    dist_info = None
     if use_dist:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
-        total_pairs, overflow = float(tt[1]), float(tmax[2])
+        total_pairs, overflow, exchange_ms = float(tt[1]), float(tmax[2]), float(tmax[3])
+        total_views = int(round(float(tt[4])))
+        # evidence of what really ran: backend and world size as the process group reports them, every rank's device
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "device": f"cuda:{dev.index}", "name": props.name,
+                "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": gathered,
+                     "exchange": "reduce_scatter_tensor(F, padded rows) + all_reduce(d)",
+                     "exchange_bytes_per_rank": int(F_store.numel() * 4 + d.numel() * 4)}
     else:
         total_pairs, overflow = float(tt[1]), float(tt[2])
+        total_views = args.steps
 
     fr = [e[0].elapsed_time(e[1]) for e in ev] if not args.serial else [0.0]
     t_front = sum(fr) / len(fr)
@@ -279,15 +319,17 @@ def main():
         achieved = b_scatter / (t_scatter * 1e-3) / 1e9
         # PMC counters cannot be collected from inside this process: `traffic` is the HBM byte count per launch of the
         # SAME kernel and workload from the committed rocprofv3 --pmc passes (tools/profile_round.sh, separate runs)
-        traffic, traffic_source = None, None
+        traffic, traffic_source, valu_insts = None, None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile)).get(args.config, {})
                 traffic = tj.get("scatter_hbm_bytes_per_launch")
+                valu_insts = tj.get("scatter_valu_wave_instructions")
                 traffic_source = "profiles/traffic.json (" + str(tj.get("source", "rocprofv3 --pmc, earlier run")) + ")"
             except Exception:
                 traffic = None
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
         scatter_kernel = (("k_blend_scatter_quarter" if gsbp_amd.Engine.fused_max_dim(W, H) > gsbp_amd.Engine.FUSED_MAX_DIM
                            else "k_blend<kFused>") + " (blend + scatter in one kernel, no weight store)" if fused_small else
                           "k_scatter_wide" if scatter_choice == "wide" else
@@ -295,12 +337,15 @@ def main():
         out = {
             "metric": "Gaussian-pixel-features/sec", "value": total_pairs * D / elapsed,
             "unit": "Gaussian-pixel-features/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg.name}: {N} Gaussians, {W}x{H} views, D={D_in}"
                                    + (f"->{D} (encoder)" if encoder is not None else "")
-                                   + f", {args.steps} views/GPU, view-sharded over {world} GPU(s), one reduce-scatter of F + all-reduce of d",
-                       "views_per_sec": world * args.steps / elapsed, "pairs_per_view": pairs_view,
+                                   + (f", the same {args.total_views} views sharded r, r+R, .. over {world} GPU(s)" if strong
+                                      else f", {args.steps} views/GPU, view-sharded over {world} GPU(s)")
+                                   + ", one reduce-scatter of F + all-reduce of d",
+                       "total_views": total_views, "views_per_sec": total_views / elapsed, "pairs_per_view": pairs_view,
                        "n_visible_per_view": n_vis, "n_isect_per_view": n_isect, "n_headers_per_view": n_hdr,
                        "binning": "alpha-ellipse bounding box (GWBP_FLAG_TIGHT_BINNING)" if tight else "gsplat 3-sigma square",
                        "overflow": overflow, "host_enqueue_ms_per_view": t_enqueue * 1e3 / args.steps,
@@ -327,9 +372,17 @@ def main():
                          # aggregate for ds_read_b64/b128 with every CU streaming
                          "lds_read_GBs": pairs_view * D * 4.0 / (t_scatter * 1e-3) / 1e9,
                          "lds_peak_GBs": 150000.0,
-                         "lds_frac": pairs_view * D * 4.0 / (t_scatter * 1e-3) / 1e9 / 150000.0},
+                         "lds_frac": pairs_view * D * 4.0 / (t_scatter * 1e-3) / 1e9 / 150000.0,
+                         # fourth ceiling, the one that binds together with the LDS time: vector instruction issue.  One
+                         # wave-instruction per SIMD per 4 cycles; SQ_INSTS_VALU of the same kernel from the committed PMC
+                         # pass (like `traffic`), SIMD-cycles = CUs x 4 x 2.4 GHz x this run's launch time
+                         "valu_wave_instructions_per_launch": valu_insts,
+                         "valu_issue_frac": (valu_insts * 4.0 / (n_cu * 4 * 2.4e9 * t_scatter * 1e-3)
+                                             if valu_insts else None)},
         }
         out["checked"] = checked
+        out["dist"] = dist_info
+        out["exchange_ms"] = exchange_ms
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder,
                                                args.cpu_views)
@@ -348,6 +401,22 @@ def main():
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run the same command line as N ranks of torch.distributed.run
+    (child processes of this one; rendezvous on 127.0.0.1, a free port), pass their output through -- rank 0's JSON line
+    stays the last line of stdout -- and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def check_results(args, gsbp_amd, eng, views, g, pool, encoder, F_rows, d_sum, row0, use_dist, dist, dev):

@@ -81,3 +81,22 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(root, f)).read()
                 assert "oracle" not in txt.replace("CPU oracle", "").replace("the oracle", "").replace(
                     "oracle bit", ""), f
+
+
+def test_profile_build_is_refused_without_explicit_opt_in(tmp_path, monkeypatch):
+    """A library whose gwbp_version() says PROFILE (ablation knobs read from the environment, results may be invalid)
+    must not be picked up through a stray GWBP_LIB: _lib.lib() refuses it unless GWBP_ALLOW_PROFILE=1."""
+    import subprocess
+    src = tmp_path / "fake.c"
+    src.write_text('const char *gwbp_version(void) { return "libgwbp gfx950 (PROFILE build)"; }\n'
+                   'const char *gwbp_last_error_string(void) { return ""; }\n')
+    so = tmp_path / "libfake_profile.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    monkeypatch.setenv("GWBP_LIB", str(so))
+    monkeypatch.delenv("GWBP_ALLOW_PROFILE", raising=False)
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.GwbpError, match="PROFILE"):
+        _lib.lib()
+    assert _lib._lib is None
+    pkg = os.path.dirname(os.path.abspath(_lib.__file__))
+    assert not [f for f in os.listdir(pkg) if "profile" in f], "no PROFILE library may sit in the package directory"

@@ -468,6 +468,44 @@ def test_pipelined_driver_equals_serial_driver(dev):
     assert rel_row_err(res[0][0], res[1][0]) <= 1e-5 and np.abs(res[0][1] - res[1][1]).max() <= 1e-4 * res[1][1].max()
 
 
+def test_view_per_stream_schedule_waits_for_late_maps(dev):
+    """Stream discipline of the view-per-stream schedule (small scene, <= 32-channel maps -> `independent`): (1) with an
+    encoder, the encode kernel must run on the encoder stream behind the `ready` event even though engine 0 is bound to
+    a view's stream; (2) without one, a feature function that produces its map LATE on the caller's stream (a long
+    kernel in front of it) must still be consumed correctly (default feature_fn_stream_safe=False: one event per view).  Compared with serial single-stream runs of the same job."""
+    cfg, sc = scene_np("T1", n_views=6)
+    d = to_dev(sc, dev)
+    vms = syn.make_cameras(cfg, n_views=6).to(dev)
+    K_in, n_out = 512, 16
+    g = torch.Generator().manual_seed(5)
+    wide = [torch.randn(cfg.height, cfg.width, K_in, generator=g).to(dev) for _ in range(6)]
+    enc = (torch.randn(K_in, n_out, generator=g) / K_in ** 0.5).to(dev)
+    ballast = torch.randn(4096, 4096, device=dev)
+
+    def late(v):  # ~ms of work on the caller's stream in front of the map
+        for _ in range(3):
+            ballast @ ballast
+        return wide[v].clone()
+
+    def late_small(v):
+        for _ in range(3):
+            ballast @ ballast
+        return (wide[v] @ enc).contiguous()
+
+    args = (d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"], cfg.width, cfg.height)
+    ref_e = gsbp_amd.create_feature_field(*args, lambda v: wide[v], K_in, encoder=enc, pipeline=False, return_partials=True)
+    ref_s = gsbp_amd.create_feature_field(*args, lambda v: (wide[v] @ enc).contiguous(), n_out, pipeline=False,
+                                          return_partials=True)
+    # (1) encoder one view ahead: only encode_ahead's `ready` event orders the encode kernel behind the late map
+    got_e = gsbp_amd.create_feature_field(*args, late, K_in, encoder=enc, pipeline=4, return_partials=True)
+    # (2) no encoder, maps produced late on the caller's stream
+    got_s = gsbp_amd.create_feature_field(*args, late_small, n_out, pipeline=4, return_partials=True)
+    for got, ref in ((got_e, ref_e), (got_s, ref_s)):
+        assert got[3]["n_pairs"] == ref[3]["n_pairs"] and got[3]["overflow"] == 0
+        assert rel_row_err(got[1].cpu().numpy(), ref[1].cpu().numpy()) <= 2e-5
+        assert np.abs((got[2] - ref[2]).cpu().numpy()).max() <= 1e-5 * float(ref[2].max())
+
+
 @pytest.mark.parametrize("D", [384, 32, 130])
 def test_scatter_nearest_upsampled_lowres_map(orc, dev, D):
     """dino variant (backproject.py:242-249): patch tokens [h,w,D] -> F.interpolate(nearest) -> scatter.  The HIP path
@@ -624,10 +662,21 @@ def test_encode_map_matches_matmul(dev, H, W, K, n):
     big[:, :W, :K] = feats.to(dev)
     out2 = eng.encode_map(big[:, :W, :K], enc.to(dev))
     assert torch.equal(out2, out)
-    # shapes the kernel does not take fall back to the library GEMM with the same result up to rounding
-    out3 = eng.encode_map(feats.to(dev)[:, :, : K - 8], enc.to(dev)[: K - 8])
-    ref3 = (feats[:, :, : K - 8].double() @ enc[: K - 8].double()).numpy()
-    assert np.abs(out3.cpu().numpy() - ref3).max() <= 2e-5
+    # shapes the kernel does not take RAISE (no silent library-GEMM fallback on the hot stage)
+    assert not gsbp_amd.Engine.can_encode_map(feats.to(dev)[:, :, : K - 8], enc.to(dev)[: K - 8])
+    with pytest.raises(gsbp_amd.GwbpError):
+        eng.encode_map(feats.to(dev)[:, :, : K - 8], enc.to(dev)[: K - 8])
+    # an explicit stream: launched there (not on the engine's bound / current stream), K = 2048 after a smaller K (the
+    # dynamic-LDS limit must follow the larger request)
+    st = torch.cuda.Stream(device=dev)
+    big_k = torch.randn(8, 8, 2048, generator=g)
+    enc_k = torch.randn(2048, n, generator=g) / 2048 ** 0.5
+    bk, ek = big_k.to(dev), enc_k.to(dev)
+    torch.cuda.synchronize(dev)
+    out4 = eng.encode_map(bk, ek, stream=st)
+    st.synchronize()
+    ref4 = (big_k.double() @ enc_k.double()).numpy()
+    assert np.abs(out4.cpu().numpy() - ref4).max() <= 2e-6 * max(1.0, np.abs(ref4).max()) * 2048 ** 0.5
 
 
 @pytest.mark.parametrize("K,n", [(512, 16), (64, 5), (32, 16)])

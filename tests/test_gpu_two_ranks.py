@@ -26,23 +26,51 @@ def test_two_ranks_on_one_gpu_match_single_process(dev):
     assert "TWO_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_bench_two_ranks_bookkeeping_on_one_device(dev):
-    """bench.py's N > 1 path (view sharding per rank, reduce-scatter of F + all-reduce of d inside the timed region, MAX /
-    SUM over ranks, the post-run check on the reduced rows) with two fresh ranks that share the one GPU over gloo
-    (--one-device: RCCL refuses two ranks on one device; the driver's real multi-GPU runs use nccl)."""
+def _bench(*extra):
+    """`python3 bench.py --gpus 2 ...` started as a PLAIN process, the way the driver runs --gpus 1: bench.py itself must
+    start the two fresh ranks (before any GPU call) and relay rank 0's JSON line."""
     import json
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--config", "C1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
-                        "--dist-backend", "gloo", "--one-device"],
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C1", "--warmup", "2",
+                        "--no-cpu-baseline", "--dist-backend", "gloo", "--one-device", *extra],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
-    j = json.loads(line)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert lines[-1].startswith('{"metric"'), lines[-3:]  # the JSON line is the LAST line of stdout
+    return json.loads(lines[-1])
+
+
+def test_bench_two_ranks_bookkeeping_on_one_device(dev):
+    """bench.py's N > 1 path (self-launch of the ranks, view sharding per rank, reduce-scatter of F + all-reduce of d
+    inside the timed region behind a join of the side streams, MAX / SUM over ranks, the post-run check on the reduced
+    rows) with two fresh ranks that share the one GPU over gloo (--one-device: RCCL refuses two ranks on one device; the
+    driver's real multi-GPU runs use nccl)."""
+    j = _bench("--steps", "6")
     assert j["n_gpus"] == 2 and j["steps"] == 6 and j["scaling"] == "weak" and j["checked"]["ok"] is True
-    assert j["config"]["overflow"] == 0 and j["value"] > 0
+    assert j["config"]["overflow"] == 0 and j["value"] > 0 and j["config"]["total_views"] == 12
+    assert j["dist"]["backend"] == "gloo" and j["dist"]["world_size"] == 2
+    assert sorted(d["rank"] for d in j["dist"]["devices"]) == [0, 1]
+    assert len({d["pid"] for d in j["dist"]["devices"]}) == 2 and j["exchange_ms"] > 0
+
+
+def test_bench_strong_scaling_mode_shards_the_same_views(dev):
+    """--total-views T (BASELINE.json configs[2]): the SAME T views sharded over the ranks; T odd -> rank 0 times 4, rank 1
+    times 3 views; the pair count must equal what one rank counts over the same 7 views."""
+    j2 = _bench("--total-views", "7")
+    assert j2["scaling"] == "strong" and j2["steps"] == 4 and j2["config"]["total_views"] == 7
+    assert j2["checked"]["ok"] is True and j2["config"]["overflow"] == 0
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--warmup", "2",
+                        "--no-cpu-baseline", "--total-views", "7"], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j1 = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert j1["scaling"] == "strong" and j1["steps"] == 7 and j1["dist"] is None
+    pairs1 = j1["config"]["pairs_per_view"] * 7
+    pairs2 = j2["value"] * (j2["ms_per_step"] * 1e-3 * j2["steps"]) / 32  # value = pairs x D / elapsed, D = 32
+    assert abs(pairs1 - pairs2) <= 1e-6 * pairs1, (pairs1, pairs2)
