@@ -326,6 +326,22 @@ class ViewPipeline:
         for a in self.accums:
             a.zero_()
 
+    def stats_async(self):
+        """(host copies of the counter accumulators, their events): enqueue a device-to-pinned-host copy of the counters behind
+        the work enqueued so far on their streams; when every event.query() is true the copies may be decoded
+        (Engine.decode_stats).  Nothing synchronises."""
+        copies, events = [], []
+        streams = self.sides if self.independent else [torch.cuda.current_stream(self.dev)]
+        for a, st in zip(self.accums, streams):
+            host = torch.empty(a.shape, dtype=a.dtype, pin_memory=True)
+            with torch.cuda.stream(st):
+                host.copy_(a, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            copies.append(host)
+            events.append(ev)
+        return copies, events
+
     def stats(self):
         """Counters summed over the views scattered so far; synchronises."""
         self.join()
@@ -334,6 +350,12 @@ class ViewPipeline:
             for k, v in Engine.decode_stats(a).items():
                 out[k] = (out.get(k, 0) | v) if k == "overflow" else out.get(k, 0) + v
         return out
+
+
+# create_feature_field looks at the accumulated overflow flags after view 2 and then every this many views (a non-blocking
+# copy of the counters, read back a few views later): a capacity overflow in view 150 of 200 restarts the job after at most
+# this many more views instead of after the last one
+OVERFLOW_CHECK_EVERY = 32
 
 
 def pipeline_depth(n_gaussians: int, width: int, height: int) -> int:
@@ -422,10 +444,22 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                     first_map = feature_fn(my_views[0])
                     fused = fuse_encoder and upsample is None and Engine.can_fuse_encoder(first_map, encoder)
                     ahead = (first_map, None) if fused else pipe.encode_ahead(first_map, encoder)
+                probe = None  # (pinned copy of the counters, event): an overflow costs at most OVERFLOW_CHECK_EVERY views
+                overflowed = False
                 for i, v in enumerate(my_views):
                     if i == 2:  # one host sync per job: views 0 and 1 are counted, pick the scatter kernel for the rest
                         st01 = pipe.stats()
+                        if st01["overflow"]:
+                            overflowed = True
+                            break
                         pipe.choose_scatter_kernel(st01["n_pairs"], st01["n_headers"])
+                    if probe is not None and all(e.query() for e in probe[1]):  # non-blocking: the copy was enqueued views ago
+                        if any(Engine.decode_stats(a)["overflow"] for a in probe[0]):
+                            overflowed = True
+                            break
+                        probe = None
+                    if i > 2 and i % OVERFLOW_CHECK_EVERY == 0 and probe is None:
+                        probe = pipe.stats_async()
                     if i + pipe.lookahead < len(my_views):
                         pipe.front(views[i + pipe.lookahead], means, quats, scales, opacities, d, sd)
                     if fused:
@@ -451,6 +485,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                                  ready=encoder is None and feature_fn_stream_safe)
                 stats = pipe.stats()
                 pipe.release()
+                assert not overflowed or stats["overflow"]
             else:
                 accum = torch.zeros(32, dtype=torch.uint8, device=dev)
                 for i, v in enumerate(my_views):

@@ -6,8 +6,8 @@ The reference rasterises every view with the DC colours (no SH, utils.py:238-249
 colors.grad[:, 0].norm() per Gaussian and keeps the Gaussians whose sum is > 0 (utils.py:251-257).  That gradient is
 -2/(3HW) * sum_p w_g(p) in every channel, so the mask is exactly  sum_v d_v[g] > 0  -- the denominator the fused
 back-projection accumulates anyway.  `prune_by_gradients` here gets it from one blend per view (no scatter at all: the
-blend leaves every record's weight sum in its header and gwbp_accumulate_d adds them); `literal=True` runs the reference's
-own loop through the drop-in rasterization() + autograd instead (slower; the tests check that both masks agree).
+blend leaves every record's weight sum in its header and gwbp_accumulate_d adds them).  The reference's own loop run through
+the drop-in rasterization() + autograd gives the same mask (tests/util.py::gradient_mask_literal, tests/test_gpu_pruning.py).
 """
 from __future__ import annotations
 
@@ -26,24 +26,12 @@ def _activated(splats: Dict[str, torch.Tensor]):
     return (splats["means"], splats["rotation"], torch.exp(splats["scaling"]), torch.sigmoid(splats["opacity"]))
 
 
-def gradient_mask(splats: Dict[str, torch.Tensor], viewmats: torch.Tensor, K: torch.Tensor, width: int, height: int,
-                  literal: bool = False) -> torch.Tensor:
+def gradient_mask(splats: Dict[str, torch.Tensor], viewmats: torch.Tensor, K: torch.Tensor, width: int,
+                  height: int) -> torch.Tensor:
     """bool[N]: Gaussians that receive weight in at least one of the views (utils.py:236-257)."""
     means, quats, scales, opac = _activated(splats)
     n, dev = means.shape[0], means.device
     width, height = int(width), int(height)  # utils.py:247-248 passes 0-d tensors
-    if literal:
-        colors = torch.cat([splats["features_dc"], splats["features_rest"]], dim=1).detach().clone()
-        colors.requires_grad = True
-        grads = torch.zeros(n, device=dev)
-        for v in range(viewmats.shape[0]):
-            out, _, _ = rasterization(means, quats, scales, opac, colors[:, 0, :], viewmats=viewmats[v][None],
-                                      Ks=K[None], width=width, height=height, want_meta=False)
-            loss = ((out.detach() + 1 - out) ** 2).mean()
-            loss.backward()
-            grads += colors.grad[:, 0].norm(dim=[1])
-            colors.grad.zero_()
-        return grads > 0
     eng = Engine(n, width, height, device=dev, tight_binning=True)
     eng.set_narrow_scatter(False)  # the blend then leaves every record's weight sum in its header
     d = torch.zeros(n, device=dev)
@@ -63,10 +51,10 @@ def gradient_mask(splats: Dict[str, torch.Tensor], viewmats: torch.Tensor, K: to
 
 
 def prune_by_gradients(splats: Dict[str, torch.Tensor], viewmats: torch.Tensor, K: torch.Tensor, width: int,
-                       height: int, literal: bool = False) -> Tuple[Dict[str, torch.Tensor], torch.Tensor]:
+                       height: int) -> Tuple[Dict[str, torch.Tensor], torch.Tensor]:
     """(pruned copy of the splats dict, mask): utils.py:222-271 with the cameras passed explicitly instead of through
     splats["colmap_project"]."""
-    mask = gradient_mask(splats, viewmats, K, width, height, literal=literal)
+    mask = gradient_mask(splats, viewmats, K, width, height)
     out = dict(splats)
     for k in _PER_GAUSSIAN:
         if k in out:

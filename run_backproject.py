@@ -30,7 +30,9 @@ def main():
     ap.add_argument("--feature-maps", default=None, help="directory with <image name>.pt tensors [H,W,D]")
     ap.add_argument("--encoder", default=None, help="[512,16] encoder tensor (.pt): backproject_compressed.py")
     ap.add_argument("--synthetic", default=None, help="run a seeded synthetic config (C1, C2, ...) instead of files")
-    ap.add_argument("--no-prune", action="store_true", help="skip the d > 0 pruning report (utils.prune_by_gradients)")
+    ap.add_argument("--no-prune", action="store_true",
+                    help="build the field on ALL Gaussians (default, like the reference's main(): prune_by_gradients -> "
+                         "test_proper_pruning -> build on the pruned scene, backproject.py:320-325)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -47,7 +49,8 @@ def main():
 
     if args.synthetic:
         cfg = syn.CONFIGS[args.synthetic]
-        means, quats, scales, opac = [t.to(dev) for t in syn.activate(syn.make_scene(cfg))]
+        splats = {k: v.to(dev) for k, v in syn.make_scene(cfg).items()}  # pre-activation, the reference's key names
+        means, quats, scales, opac = syn.activate(splats)
         K, viewmats, W, H, dim = syn.intrinsics(cfg), syn.make_cameras(cfg), cfg.width, cfg.height, cfg.feat_dim
         encoder = syn.make_encoder(cfg).to(dev) if cfg.encoder_dim else None
 
@@ -58,6 +61,7 @@ def main():
                                           data_factor=args.data_factor, rasterizer=args.rasterizer)
         means, quats = splats["means"].to(dev).float(), splats["rotation"].to(dev).float()
         scales, opac = torch.exp(splats["scaling"]).to(dev).float(), torch.sigmoid(splats["opacity"]).to(dev).float()
+        splats = {k: (v.to(dev).float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in splats.items()}
         K = splats["camera_matrix"]
         W, H = int(K[0, 2] * 2), int(K[1, 2] * 2)  # backproject.py:85-86
         images = sorted(splats["colmap_project"].images.values(), key=lambda im: im.name)  # backproject.py:74
@@ -73,18 +77,36 @@ def main():
             return f if f.shape[:2] == (H, W) else torch.nn.functional.interpolate(
                 f.permute(2, 0, 1)[None], size=(H, W), mode="bilinear")[0].permute(1, 2, 0)
 
+    # backproject.py:323-325: splats_optimized = prune_by_gradients(splats); test_proper_pruning(splats, splats_optimized);
+    # the field is then built on the PRUNED scene.  The mask costs one blend per view (no scatter); every rank computes it
+    # over all views (it must be identical everywhere: the accumulators are reduced row by row afterwards).
+    n_all = means.shape[0]
+    keep = None
+    if not args.no_prune:
+        vm_dev, K_dev = viewmats.to(dev), K.to(dev)
+        keep = gsbp_amd.pruning.gradient_mask(splats, vm_dev, K_dev, W, H)
+        if rank == 0:
+            print("Total splats", keep.numel())  # utils.py:258-260
+            print("Pruned", int((~keep).sum()), "splats")
+            print("Remaining", int(keep.sum()), "splats")
+        if "features_dc" in splats and rank == 0:  # utils.test_proper_pruning renders with the SH colours (checkpoints only)
+            pruned = {k: (v[keep] if k in gsbp_amd.pruning._PER_GAUSSIAN else v) for k, v in splats.items()}
+            rep = gsbp_amd.check_proper_pruning(splats, pruned, vm_dev, K_dev, W, H)
+            print("Percentage pruned: ", rep["percentage_pruned"])  # utils.py:348-359
+            print("Max pixel error: ", rep["max_pixel_error"])
+            print("Total pixel error: ", rep["total_pixel_error"])
+        means, quats, scales, opac = means[keep], quats[keep], scales[keep], opac[keep]
+
     reduction = "mean" if args.feature == "dino" else "sum"  # backproject.py:263,283 vs :127,145
     out, F, d, stats = gsbp_amd.create_feature_field(means, quats, scales, opac, viewmats, K, W, H, feature_fn, dim,
                                                      reduction=reduction, encoder=encoder, return_partials=True,
                                                      verbose=True)
     if rank == 0:
-        if not args.no_prune:
-            keep = gsbp_amd.prune_mask(d)
-            print("Total splats", keep.numel())  # utils.py:258-260
-            print("Pruned", int((~keep).sum()), "splats")
-            print("Remaining", int(keep.sum()), "splats")
         name = "features_lseg_compressed.pt" if encoder is not None else f"features_{args.feature}.pt"
-        print("saved", scene_io.save_features(out.cpu(), args.results_dir, name), tuple(out.shape), stats)
+        print("saved", scene_io.save_features(out.cpu(), args.results_dir, name), tuple(out.shape),
+              f"(of {n_all} Gaussians)", stats)
+        if keep is not None:  # the rows of the features file are the kept Gaussians, in order (like the reference's)
+            torch.save(keep.cpu(), os.path.join(args.results_dir, "prune_mask.pt"))
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -1,0 +1,33 @@
+"""run_backproject.py, the counterpart of the reference's main() (backproject.py:301-336): prune_by_gradients ->
+(test_proper_pruning when the checkpoint has SH colours) -> feature field of the PRUNED scene -> features_<kind>.pt.
+Runs the CLI as a child process on the synthetic C1 scene, with and without --no-prune: the kept Gaussians' rows must
+agree (a pruned Gaussian has no weight in any view, so it cannot change anyone's transmittance)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tmp, *flags):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_backproject.py"), "--synthetic", "C1", "--results-dir",
+                        str(tmp), *flags], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_cli_prunes_first_like_the_reference_main(dev, tmp_path):
+    a, b = tmp_path / "pruned", tmp_path / "all"
+    out = _run(a)
+    assert "Total splats 10000" in out and "Remaining" in out and "Time taken for feature backprojection" in out
+    _run(b, "--no-prune")
+    keep = torch.load(a / "prune_mask.pt")
+    fa, fb = torch.load(a / "features_lseg.pt"), torch.load(b / "features_lseg.pt")
+    assert keep.dtype == torch.bool and keep.shape == (10000,) and not (b / "prune_mask.pt").exists()
+    assert 0 < int(keep.sum()) < 10000 and fa.shape == (int(keep.sum()), 32) and fb.shape == (10000, 32)
+    assert float((fa - fb[keep]).abs().max()) <= 1e-5  # unit rows
+    assert float(fb[~keep].abs().max()) == 0.0          # never-seen Gaussians: 0/0 -> NaN -> 0 (backproject.py:169)

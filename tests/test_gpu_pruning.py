@@ -6,6 +6,7 @@ import torch
 
 import gsbp_amd
 from gsbp_amd import synthetic as syn
+from util import gradient_mask_literal
 
 pytestmark = pytest.mark.gpu
 
@@ -23,7 +24,7 @@ def test_prune_by_gradients_fused_mask_equals_literal_loop_and_renders_survive(d
     splats = _splats(cfg, dev)
     vms, K = syn.make_cameras(cfg).to(dev), syn.intrinsics(cfg).to(dev)
     pruned, mask = gsbp_amd.prune_by_gradients(splats, vms, K, cfg.width, cfg.height)
-    _, mask_lit = gsbp_amd.prune_by_gradients(splats, vms, K, K[0, 2] * 2, K[1, 2] * 2, literal=True)  # 0-d tensors
+    mask_lit = gradient_mask_literal(splats, vms, K, K[0, 2] * 2, K[1, 2] * 2)  # 0-d tensors (utils.py:247-248)
     assert torch.equal(mask, mask_lit)
     kept = int(mask.sum())
     assert 0 < kept < cfg.n_gaussians and pruned["means"].shape[0] == kept and pruned["features_rest"].shape[0] == kept

@@ -35,3 +35,23 @@ def sort_pairs(gid, pix, w):
     key = gid.astype(np.int64) * (1 << 32) + pix.astype(np.int64)
     o = np.argsort(key, kind="stable")
     return key[o], w[o]
+
+
+def gradient_mask_literal(splats, viewmats, K, width, height):
+    """TEST SUPPORT: the reference's own pruning loop (utils.py:236-257) run through the drop-in rasterization() +
+    autograd -- DC colours, pseudo-loss ((out.detach() + 1 - out) ** 2).mean(), colors.grad[:, 0].norm() summed over the
+    views, mask = sum > 0.  The product (gsbp_amd.pruning.gradient_mask) gets the same mask from one blend per view."""
+    from gsbp_amd import rasterization
+    means, quats = splats["means"], splats["rotation"]
+    scales, opac = torch.exp(splats["scaling"]), torch.sigmoid(splats["opacity"])
+    colors = torch.cat([splats["features_dc"], splats["features_rest"]], dim=1).detach().clone()
+    colors.requires_grad = True
+    grads = torch.zeros(means.shape[0], device=means.device)
+    for v in range(viewmats.shape[0]):
+        out, _, _ = rasterization(means, quats, scales, opac, colors[:, 0, :], viewmats=viewmats[v][None],
+                                  Ks=K[None], width=width, height=height, want_meta=False)
+        loss = ((out.detach() + 1 - out) ** 2).mean()
+        loss.backward()
+        grads += colors.grad[:, 0].norm(dim=[1])
+        colors.grad.zero_()
+    return grads > 0
