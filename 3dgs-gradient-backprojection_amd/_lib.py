@@ -49,6 +49,7 @@ class Stats(C.Structure):
 FLAG_TIGHT_BINNING = 1  # GWBP_FLAG_TIGHT_BINNING (include/gwbp.h)
 FLAG_FRONT_PRIORITY = 2  # GWBP_FLAG_FRONT_PRIORITY
 FLAG_NARROW_SCATTER = 4  # GWBP_FLAG_NARROW_SCATTER
+FLAG_GROUP_SCATTER = 8  # GWBP_FLAG_GROUP_SCATTER: block-sparse scatter on the matrix cores (D % 128 == 0)
 
 
 class GwbpError(RuntimeError):

@@ -36,6 +36,19 @@ def reduce_partials(F: torch.Tensor, d: torch.Tensor) -> None:
         dist.all_reduce(d, op=dist.ReduceOp.SUM)
 
 
+def encode_features(eng: Engine, feats: torch.Tensor, encoder: torch.Tensor, **kw) -> torch.Tensor:
+    """backproject_compressed.py:127 for the DRIVER: the hand-written kernel (Engine.encode_map) for every shape it takes --
+    which includes the reference's 512 -> 16 encoder -- and, explicitly and only here, torch's library GEMM for encoders
+    outside its domain (K % 16 != 0, more than 16 outputs, strided channels).  Engine.encode_map itself never falls back."""
+    if Engine.can_encode_map(feats, encoder):
+        return eng.encode_map(feats, encoder, **kw)
+    stream = kw.get("stream")
+    if stream is None:
+        return feats @ encoder
+    with torch.cuda.stream(stream):
+        return feats @ encoder
+
+
 def rows_per_rank(n: int, world: int) -> int:
     """Rows of F every rank owns after the reduce-scatter: ceil(n / world); the last rank's block may be short."""
     return -(-n // world)
@@ -118,8 +131,9 @@ class ViewPipeline:
 
     def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None,
                  allow_wide: bool = True, scatter_workgroups: Optional[int] = None, side_priority: int = -1,
-                 front_priority: Optional[bool] = None, fuse_small: bool = True):
+                 front_priority: Optional[bool] = None, fuse_small: bool = True, allow_groups: bool = True):
         self.dev = torch.device(device)
+        self.allow_groups = bool(allow_groups)
         self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev, tight_binning=True)
                                                   for _ in range(2)]
         # Scatter grid under overlap: one persistent workgroup per CU is the measured optimum once the front stage is
@@ -178,14 +192,20 @@ class ViewPipeline:
         are pending: every Engine remembers whether the view in its workspace was blended with the half-tile lists, and
         scatters a view blended without them through the 128-channel kernel (front() likewise recorded whether it has
         already added that view's denominators)."""
-        wide = self.allow_wide and self.scatter_dim is not None and self.scatter_dim % 256 == 0
+        # the block-sparse (matrix-core) scatter: every engine of the pipeline was built with group_scatter=True and the
+        # channel count suits it; it leaves the vector ALUs to the front stage, so no raised priority is needed
+        groups = (self.allow_groups and self.scatter_dim is not None and self.scatter_dim % 128 == 0
+                  and all(e.group_capable for e in self.eng))
+        wide = not groups and self.allow_wide and self.scatter_dim is not None and self.scatter_dim % 256 == 0
         if wide and n_pairs is not None and n_headers:
             wide = n_pairs / n_headers >= self.WIDE_MIN_PAIRS_PER_RECORD
-        self.wide = wide
+        self.wide, self.groups = wide, groups
         for e in self.eng:
+            if e.group_capable:
+                e.set_group_scatter(groups)
             e.set_narrow_scatter(not wide)
             e.set_front_priority(wide if self.front_priority is None else bool(self.front_priority))
-        return "wide" if wide else "narrow"
+        return "groups" if groups else "wide" if wide else "narrow"
 
     def front(self, view, means, quats, scales, opacities, d=None, scale_d=1.0):
         """d (optional): the denominator accumulator.  With the 256-channel scatter kernel chosen, the view's share of d
@@ -211,7 +231,7 @@ class ViewPipeline:
             e = self.eng[b]
             e.project(view, means, quats, scales, opacities)
             e.bin_sort(view)
-            d_done = d is not None and self.wide and not self.fuse_small
+            d_done = d is not None and (self.wide or self.groups) and not self.fuse_small
             if not self.fuse_small:
                 e.blend_weights(view, d=d if d_done else None, scale_d=scale_d)
             self.ev_front[b].record(side)
@@ -239,7 +259,7 @@ class ViewPipeline:
             per_cu = self.ENCODER_WORKGROUPS_PER_CU or (2.0 if self.fuse_small else 1.0)
             # stream=: in the view-per-stream schedule eng[0] is BOUND to sides[0]; the encoder must run here, behind
             # `ready`, and `done` must cover it
-            out = self.eng[0].encode_map(feats, encoder, workgroups=max(1, int(per_cu * n_cu)), stream=self.enc_stream)
+            out = encode_features(self.eng[0], feats, encoder, workgroups=max(1, int(per_cu * n_cu)), stream=self.enc_stream)
             done = torch.cuda.Event()
             done.record(self.enc_stream)
         feats.record_stream(self.enc_stream)
@@ -373,7 +393,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                          views: Optional[Sequence[int]] = None, view_fn=None, pipeline: bool = True,
                          return_partials: bool = False, verbose: bool = False, upsample: Optional[str] = None,
                          gather: bool = True, allow_wide: bool = True, fuse_encoder: bool = False,
-                         fuse_small: bool = True, feature_fn_stream_safe: bool = False):
+                         fuse_small: bool = True, feature_fn_stream_safe: bool = False, allow_groups: bool = True):
     """Build the [N, dim_out] per-Gaussian feature field.
 
     means/quats/scales/opacities: post-activation Gaussians (backproject.py:55-57), device tensors.
@@ -393,6 +413,8 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     kernel one view ahead on a third stream (gwbp_encode_map).
     fuse_small: maps of at most 16 channels (after the encoder) are blended AND scattered by one kernel
     (gwbp_blend_scatter: no weight store, no scatter kernel; C5 1.96 -> 1.42 ms/view); False keeps the two-kernel form.
+    allow_groups: D % 128 == 0 full-resolution maps go through the block-sparse scatter on the matrix cores
+    (GWBP_FLAG_GROUP_SCATTER, csrc/scatter_mfma.hip); False keeps the vector kernels (allow_wide picks between them).
     feature_fn_stream_safe: STREAM CONTRACT of feature_fn.  False (default): feature_fn runs on the caller's current stream
     and every map is handed to its consumer stream with an event -- any feature function is safe, including one that
     returns a prefetched tensor, reuses a static output buffer or replays a graph (the buffer must still not be overwritten
@@ -424,14 +446,20 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     t0 = time.time()
     stats: Dict[str, int] = {}
     if view_fn is None:
-        eng = engine or Engine(n, width, height, device=dev, tight_binning=True)  # same F and d, shorter tile lists
+        # allow_groups: the block-sparse (matrix-core) scatter for D % 128 == 0 full-resolution maps; an engine handed in by
+        # the caller decides for itself (Engine(group_scatter=...))
+        want_groups = allow_groups and d_out % 128 == 0 and upsample is None
+        eng = engine or Engine(n, width, height, device=dev, tight_binning=True,  # same F and d, shorter tile lists
+                               group_scatter=want_groups)
         for attempt in range(6):  # a capacity overflow invalidates the accumulators: grow the workspace, start over
             if pipeline and len(my_views) > 1:
                 depth = pipeline_depth(n, width, height) if pipeline is True else max(2, int(pipeline))
                 pipe = ViewPipeline(n, width, height, dev, scatter_dim=d_out,
                                     allow_wide=allow_wide, fuse_small=fuse_small and not (fuse_encoder and encoder is not None),
+                                    allow_groups=want_groups,
                                     engines=[eng] + [Engine(n, width, height, device=dev, tight_binning=eng.tight_binning,
-                                                            isect_cap=eng.isect_cap, pair_cap=eng.pair_cap)
+                                                            isect_cap=eng.isect_cap, pair_cap=eng.pair_cap,
+                                                            group_scatter=eng.group_capable)
                                                      for _ in range(depth - 1)])
                 views = [eng.view(vm_host[v], K_host, width, height) for v in my_views]
                 for j in range(min(pipe.lookahead, len(my_views))):
@@ -466,7 +494,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                         # the encoder is applied inside the scatter kernel's slab staging: no [H,W,dim_out] map at all
                         feats = ahead[0] if i == 0 else feature_fn(v)
                         if not Engine.can_fuse_encoder(feats, encoder):
-                            feats, fenc = eng.encode_map(feats, encoder), None
+                            feats, fenc = encode_features(eng, feats, encoder), None
                         else:
                             fenc = encoder
                         pipe.scatter(feats, F, d, sf, sd, encoder=fenc)
@@ -491,7 +519,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                 for i, v in enumerate(my_views):
                     feats = feature_fn(v)
                     if encoder is not None:
-                        feats = eng.encode_map(feats, encoder)
+                        feats = encode_features(eng, feats, encoder)
                     view = eng.view(vm_host[v], K_host, width, height)
                     if upsample is None and fuse_small and Engine.can_blend_scatter(feats):
                         eng.project(view, means, quats, scales, opacities)

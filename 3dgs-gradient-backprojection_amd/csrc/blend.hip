@@ -28,11 +28,12 @@ constexpr int kBatch = 64;
 // What a contributing record turns into.
 //   kStore:  entries {w, pixel} + Header in the weight store (read by k_scatter_full / k_scatter / k_render_*)
 //   kHalves: the same plus the half-tile record lists and weight sums the 256-channel scatter kernel reads
+//   kGroups: kStore plus the weight sums (no half-tile lists): what the block-sparse scatter's grouping pass reads
 //   kFused:  NO store: the record's sums  F[gid, :D] += sum_p w f[p, :],  d[gid] += sum_p w  are formed right here from
 //            the tile's pixels held in registers (D <= 16: 4 pixels x 16 channels = 64 VGPRs per lane) and added to F / d
 //            with one atomic instruction -- the small-D variants (backproject_compressed.py:127-165: D = 16) then need
 //            neither the 0.8 GB store nor a scatter kernel.
-enum BlendMode { kStore = 0, kHalves = 1, kFused = 2 };
+enum BlendMode { kStore = 0, kHalves = 1, kFused = 2, kGroups = 3 };
 constexpr int kFusedCh = 16;
 
 struct FusedArgs { // kFused only
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                                               float *__restrict__ d_out, float scale_d, FusedArgs fu)
 {
     constexpr bool HALVES = MODE == kHalves;
+    constexpr bool WSUM = MODE == kHalves || MODE == kGroups; // the record's weight sum in its header (+ d[gid] right here)
     front_priority(prio);
     __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
     __shared__ float4 s_b[kBatch]; // ca, cb, cc, strip mask
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 // only the 256-channel scatter kernel wants the record's weight sum and the half-tile lists; computing them
                 // regardless cost the blend 15-20 % (and 7 VGPRs), hence the template parameter
                 float wsum = 0.f; // the record's share of d[gid] (k_accum_d)
-                if constexpr (HALVES) {
+                if constexpr (WSUM) {
                     float wl = 0.f;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     h.wsum = (u32)__float_as_int(wsum), h.pad = 0;
                     h.mask[0] = m[0], h.mask[1] = m[1], h.mask[2] = m[2], h.mask[3] = m[3];
                     headers[beg + hdr_n] = h;
-                    if constexpr (HALVES) { // gwbp_blend_weights_d: the record's share of d[gid] right here (no k_accum_d)
+                    if constexpr (WSUM) { // gwbp_blend_weights_d: the record's share of d[gid] right here (no k_accum_d)
                         if (d_out) // (spelled as the instruction: hipcc wraps a single-lane atomicAdd in its wave-aggregation code)
                             asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(d_out + h.gid), "v"(wsum * scale_d) : "memory");
                     }
@@ -659,7 +661,7 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
         fu.feats = M->p, fu.fs_y = M->fs_y, fu.fs_x = M->fs_x, fu.D = D, fu.scale_f = scale_f, fu.F = F;
         fu.vec4 = (D % 4 == 0 && M->fs_y % 4 == 0 && M->fs_x % 4 == 0 && (reinterpret_cast<uintptr_t>(M->p) & 15) == 0) ? 1 : 0;
     }
-    if (!fused && d && (L.flags & GWBP_FLAG_NARROW_SCATTER))
+    if (!fused && d && (L.flags & GWBP_FLAG_NARROW_SCATTER) && !(L.flags & GWBP_FLAG_GROUP_SCATTER))
         return set_error(GWBP_EINVAL, "gwbp_blend_weights_d needs a blend without GWBP_FLAG_NARROW_SCATTER (no weight sums)");
     const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
     const int n_tiles = V.tile_w * V.tile_h;
@@ -682,6 +684,8 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
 #undef GWBP_QUARTER
     } else if (fused)
         GWBP_BLEND(kFused);
+    else if (L.flags & GWBP_FLAG_GROUP_SCATTER)
+        GWBP_BLEND(kGroups);
     else if (L.flags & GWBP_FLAG_NARROW_SCATTER)
         GWBP_BLEND(kStore);
     else
@@ -689,8 +693,12 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
 #undef GWBP_BLEND
     if (!fused)
         hipLaunchKernelGGL(k_pool_stats, dim3(1), dim3(1), 0, s, W.shards, W.counters,
-                           (L.flags & GWBP_FLAG_NARROW_SCATTER) ? 0u : kBlendHalves);
-    return check_hip(hipGetLastError(), "blend launch");
+                           (L.flags & GWBP_FLAG_GROUP_SCATTER) ? kBlendGroups
+                           : (L.flags & GWBP_FLAG_NARROW_SCATTER) ? 0u : kBlendHalves);
+    int rc = check_hip(hipGetLastError(), "blend launch");
+    if (rc == GWBP_OK && !fused && (L.flags & GWBP_FLAG_GROUP_SCATTER))
+        rc = launch_pack_groups(L, W, V, s); // record groups + dense operand tables of the block-sparse scatter
+    return rc;
 }
 
 int launch_dump_pairs(const Layout &L, const Ws &W, const ViewDev &V, int64_t cap, int32_t *gid, int32_t *pix,

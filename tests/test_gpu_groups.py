@@ -1,0 +1,126 @@
+"""The block-sparse scatter on the matrix cores (GWBP_FLAG_GROUP_SCATTER, csrc/scatter_mfma.hip): k_group_sort + k_pack
+behind the blend, k_scatter_mfma as the scatter.  Same semantics as the vector kernels: F[g,:] += sum_p w_g(p) feats[p,:]
+(backproject.py:127-131), every record's sum in ascending pixel order, exact fp32 (v_mfma_f32_16x16x4_f32 is a k-ordered
+fmaf chain; a zero weight adds +-0).  Checked against the CPU oracle, against the 128-channel vector kernel on the SAME
+weight store, on non-finite feature values (0 x NaN must not leak into records that do not touch the pixel) and at the
+capacity edge."""
+import numpy as np
+import pytest
+import torch
+
+from util import npy, rel_row_err, scene_np, to_dev
+
+import gsbp_amd
+from gsbp_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _blend(eng, d, cfg, v):
+    view = eng.view(d["vms"][v].cpu(), d["K"].cpu(), cfg.width, cfg.height)
+    eng.project(view, d["means"], d["quats"], d["scales"], d["opac"])
+    eng.bin_sort(view)
+    eng.blend_weights(view)
+    return view
+
+
+@pytest.mark.parametrize("name,D", [("T1", 128), ("T1", 384), ("C1", 256), ("T0", 128)])
+def test_group_scatter_matches_oracle_and_vector_kernel(orc, dev, name, D):
+    cfg, sc = scene_np(name)
+    d, h = to_dev(sc, dev), npy(sc)
+    feats = torch.randn(cfg.height, cfg.width, D, generator=torch.Generator().manual_seed(D))
+    eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, group_scatter=True)
+    view = _blend(eng, d, cfg, 0)
+    st = eng.stats()
+    assert st["overflow"] == 0 and st["reserved"] == 3  # store + record groups
+    F = torch.zeros(cfg.n_gaussians, D, device=dev)
+    dd = torch.zeros(cfg.n_gaussians, device=dev)
+    eng.scatter(view, feats.to(dev), F, dd)
+    # the same weight store through the 128-channel vector kernel
+    eng.set_group_scatter(False)
+    F2 = torch.zeros_like(F)
+    d2 = torch.zeros_like(dd)
+    eng.scatter(view, feats.to(dev), F2, d2)
+    assert eng.stats()["overflow"] == 0
+    Fr = np.zeros((cfg.n_gaussians, D), np.float64)
+    dr = np.zeros(cfg.n_gaussians, np.float64)
+    orc.backproject_view(h["means"], h["quats"], h["scales"], h["opac"], h["vms"][0], h["K"], cfg.width, cfg.height,
+                         feats.numpy(), Fr, dr)
+    assert rel_row_err(F.cpu().numpy(), Fr) <= TOL and rel_row_err(dd.cpu().numpy()[:, None], dr[:, None]) <= TOL
+    # per record both kernels run the same fmaf chain; only the order of the flush atomics differs
+    assert rel_row_err(F.cpu().numpy(), F2.cpu().numpy().astype(np.float64)) <= 2e-6
+    assert torch.allclose(dd, d2, rtol=1e-5, atol=0)
+    # a second scatter of the same view (the queues re-arm themselves) and scale_f
+    F3 = torch.zeros_like(F)
+    eng.set_group_scatter(True)
+    eng.scatter(view, feats.to(dev), F3, None, scale_f=0.5)
+    assert rel_row_err(2.0 * F3.cpu().numpy(), F.cpu().numpy().astype(np.float64)) <= 2e-6
+
+
+def test_group_scatter_keeps_nan_where_the_reference_has_it(dev):
+    """feats / feats.norm() of an all-zero pixel is NaN in the reference (backproject.py:109): it reaches exactly the
+    Gaussians with weight on that pixel.  A dense operand table multiplies every pixel of the group's union by every record
+    (0 x NaN = NaN), so tiles whose staged pixels are not all finite take the exact sparse path: the NaN pattern and the
+    finite rows must equal the vector kernel's."""
+    cfg, sc = scene_np("T1")
+    d = to_dev(sc, dev)
+    D = 128
+    feats = torch.randn(cfg.height, cfg.width, D, generator=torch.Generator().manual_seed(3))
+    feats[10, 20, :] = float("nan")
+    feats[50, 100, 7] = float("inf")
+    feats[100, 150, 64:] = float("-inf")
+    eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, group_scatter=True)
+    view = _blend(eng, d, cfg, 0)
+    F = torch.zeros(cfg.n_gaussians, D, device=dev)
+    eng.scatter(view, feats.to(dev), F, None)
+    eng.set_group_scatter(False)
+    F2 = torch.zeros_like(F)
+    eng.scatter(view, feats.to(dev), F2, None)
+    a, b = F.cpu(), F2.cpu()
+    assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.isinf(a), torch.isinf(b))
+    assert int(torch.isnan(a).any(dim=1).sum()) > 0  # the poisoned pixels are covered by some Gaussian
+    fin = torch.isfinite(a)
+    assert float(((a - b)[fin]).abs().max()) <= 1e-5 * float(b[fin].abs().max())
+
+
+def test_group_tables_overflow_is_flagged_and_grown(dev):
+    """Block capacity follows pair_cap: a workspace with a pair_cap that just fits the weight store overflows the dense tables
+    (gwbp_stats.overflow bit 3); create_feature_field grows and restarts, the result equals the roomy run's."""
+    cfg, sc = scene_np("C1")
+    d = to_dev(sc, dev)
+    D = 128
+    vms = syn.make_cameras(cfg).to(dev)
+    maps = [torch.randn(cfg.height, cfg.width, D, generator=torch.Generator().manual_seed(v)).to(dev) for v in range(4)]
+    args = (d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"], cfg.width, cfg.height, lambda v: maps[v], D)
+    ref, Fr, dr, st_r = gsbp_amd.create_feature_field(*args, return_partials=True)
+    assert st_r["overflow"] == 0
+    probe = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, group_scatter=True)
+    view = _blend(probe, d, cfg, 0)
+    used = probe.stats()["n_pairs"]
+    small = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, group_scatter=True,
+                            pair_cap=max(1 << 15, int(1.3 * used)), isect_cap=probe.isect_cap)
+    _blend(small, d, cfg, 0)
+    st = small.stats()
+    if not st["overflow"] & 8:
+        pytest.skip("the dense tables fit this pair_cap: nothing to grow")
+    out, F, dd, st2 = gsbp_amd.create_feature_field(*args, engine=small, return_partials=True)
+    assert st2["overflow"] == 0 and small.pair_cap > int(1.3 * used)
+    assert rel_row_err(F.cpu().numpy(), Fr.cpu().numpy().astype(np.float64)) <= 2e-6
+
+
+def test_pipelined_driver_uses_groups_and_matches_vector_kernels(dev):
+    cfg, sc = scene_np("T1", n_views=5)
+    d = to_dev(sc, dev)
+    D = 256
+    vms = syn.make_cameras(cfg, n_views=5).to(dev)
+    maps = [torch.randn(cfg.height, cfg.width, D, generator=torch.Generator().manual_seed(v)).to(dev) for v in range(5)]
+    args = (d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"], cfg.width, cfg.height, lambda v: maps[v], D)
+    res = []
+    for kw in (dict(), dict(allow_groups=False), dict(allow_groups=False, allow_wide=False), dict(pipeline=False)):
+        out, F, dd, st = gsbp_amd.create_feature_field(*args, return_partials=True, **kw)
+        assert st["overflow"] == 0
+        res.append((F.cpu().numpy().astype(np.float64), dd.cpu().numpy(), st["n_pairs"]))
+    for r in res[1:]:
+        assert r[2] == res[0][2]
+        assert rel_row_err(res[0][0], r[0]) <= 1e-5 and np.abs(res[0][1] - r[1]).max() <= 1e-4 * r[1].max()

@@ -211,3 +211,39 @@ def test_finalize_matches_reference_lines(orc):
     x[torch.isnan(x)] = 0
     assert np.abs(out - x.numpy()).max() < 2e-7 and np.all(out[7] == 0)
     assert np.abs(gsbp_amd.finalize_reference(gf, torch.from_numpy(d).float()).numpy() - out).max() < 2e-7
+
+
+CAPTURES = [("gsplat_g0.npz", None), ("gsplat_t1.npz", "T1")]
+
+
+@pytest.mark.parametrize("fname,cfgname", CAPTURES)
+def test_oracle_against_gsplat_capture(orc, fname, cfgname):
+    """PINS THE ORACLE when a capture of real gsplat 1.4.0 output exists (tools/capture_gsplat_fixture.py, run by a
+    maintainer with CUDA; only the resulting .npz data is committed).  Without the file the oracle stays PARITY UNPINNED
+    and this test is skipped.  Threshold rows (pairs exactly at the alpha >= 1/255 or T' <= 1e-4 cut) are expected over
+    1e-4 at the rate profiles/r2_sensitivity_C1.json measured for a 2-ulp exp (2-3 rows in 10 000): the bar is on the
+    bulk -- 99 % of the rows within 1e-4, at most 0.2 % of the rows (and never more than 1e-2) beyond it."""
+    from util import capture_report
+    path = os.path.join(os.path.dirname(GOLD), fname)
+    if not os.path.exists(path):
+        pytest.skip(f"{fname} not captured yet (needs CUDA + gsplat==1.4.0): oracle parity stays unpinned")
+    cap = dict(np.load(path))
+    if cfgname is None:
+        g = dict(np.load(GOLD))
+        W, H, D = W0, H0, 8
+        feats = g["feats"]
+    else:
+        cfg = syn.CONFIGS[cfgname]
+        m, q, s, o = [t.numpy() for t in syn.activate(syn.make_scene(cfg))]
+        g = dict(means=m, quats=q, scales=s, opac=o, K=syn.intrinsics(cfg).numpy(), vms=syn.make_cameras(cfg).numpy())
+        W, H, D = cfg.width, cfg.height, cfg.feat_dim
+        feats = [syn.make_feature_map(cfg, v).numpy() for v in range(cfg.n_views)]
+    out, F, d, _ = orc.backproject_oracle(g["means"], g["quats"], g["scales"], g["opac"], g["vms"], g["K"], W, H,
+                                          lambda v: feats[v], D)
+    proj = orc.project(g["means"], g["quats"], g["scales"], g["vms"][0], g["K"], W, H)
+    rep = capture_report(cap, out, F, d, proj["radii"], proj["means2d"], proj["conics"], proj["depths"])
+    print("oracle vs gsplat capture", fname, rep)
+    for k in ("F", "d", "out"):
+        assert rep[k]["p99"] <= 1e-4, (k, rep[k])
+        assert rep[k]["rows_over_1e-4"] <= max(1, int(0.002 * rep[k]["rows"])) and rep[k]["max"] <= 1e-2, (k, rep[k])
+    assert rep.get("radii", {}).get("visible_equal", True), rep["radii"]

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""PATH TO PINNED PARITY: capture what the REAL reference arithmetic (gsplat 1.4.0, CUDA) produces on this repository's
+golden inputs, so that the oracle and the HIP kernels can be compared with it.
+
+Cannot run in this project's containers (gsplat is CUDA-only, not vendored, no network).  A maintainer with an NVIDIA GPU
+runs, once:
+
+    pip install gsplat==1.4.0 torch numpy
+    python tools/capture_gsplat_fixture.py            # reads tests/golden/g0.npz (+ the seeded T1 scene if this package
+                                                      # is importable), writes tests/golden/gsplat_g0.npz [, gsplat_t1.npz]
+
+and commits the resulting .npz DATA files (inputs are already committed; nothing of gsplat's or the reference's source
+travels).  tests/test_oracle.py::test_oracle_against_gsplat_capture (CPU) and tests/test_gpu_parity.py::
+test_hip_against_gsplat_capture (GPU) consume the files when present and are skipped otherwise.
+
+What is captured, per view, mirrors the reference's per-view body (backproject.py:115-151) literally:
+  * rasterization(means, quats, scales, opacities, zeros[N, D], viewmat[None], K[None], width=W, height=H)
+    -> (render * feats).sum().backward() -> colors.grad                      = F_v   [N, D]
+  * rasterization(..., zeros[N, 3], ...) -> render.sum().backward() -> grad[:, 0] = d_v   [N]
+  * the forward meta of view 0: means2d, radii, conics, depths, isect_ids, flatten_ids (+ tile geometry), render alphas
+and the finalised field  normalize((sum F_v) / (1e-12 + sum d_v)), NaN -> 0  (backproject.py:62-63,166-169).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def capture(inp, out_path):
+    import torch
+    from gsplat import rasterization  # the reference's import (backproject.py:7)
+    import gsplat
+    dev = torch.device("cuda")
+    t = {k: torch.from_numpy(np.asarray(inp[k])).to(dev) for k in ("means", "quats", "scales", "opac", "K", "vms", "feats")}
+    N, (V, H, W, D) = t["means"].shape[0], t["feats"].shape
+    F = torch.zeros(N, D, device=dev)
+    d = torch.zeros(N, device=dev)
+    meta0, alphas0 = None, None
+    Fv, dv = [], []
+    for v in range(V):
+        colors = torch.zeros(N, D, device=dev, requires_grad=True)
+        out, alphas, meta = rasterization(t["means"], t["quats"], t["scales"], t["opac"], colors, t["vms"][v][None],
+                                          t["K"][None], width=W, height=H)
+        (out[0] * t["feats"][v]).sum().backward()
+        Fv.append(colors.grad.detach().clone())
+        c3 = torch.zeros(N, 3, device=dev, requires_grad=True)
+        out3, _, _ = rasterization(t["means"], t["quats"], t["scales"], t["opac"], c3, t["vms"][v][None], t["K"][None],
+                                   width=W, height=H)
+        out3.sum().backward()
+        dv.append(c3.grad[:, 0].detach().clone())
+        F += Fv[-1]
+        d += dv[-1]
+        if v == 0:
+            meta0, alphas0 = meta, alphas
+    x = F / (1e-12 + d)[:, None]
+    x = x / x.norm(dim=-1, keepdim=True)
+    x[torch.isnan(x)] = 0
+
+    def m(key):
+        val = meta0.get(key)
+        return None if val is None else val.detach().cpu().numpy()
+
+    save = dict(gsplat_version=np.array(gsplat.__version__), torch_version=np.array(torch.__version__),
+                device=np.array(torch.cuda.get_device_name(0)),
+                F=F.cpu().numpy(), d=d.cpu().numpy(), out=x.cpu().numpy(),
+                F_views=torch.stack(Fv).cpu().numpy(), d_views=torch.stack(dv).cpu().numpy(),
+                v0_alphas=alphas0[0, ..., 0].detach().cpu().numpy())
+    # packed=True (gsplat's default) returns per-visible-Gaussian arrays + gaussian_ids; both layouts are stored as given
+    for key in ("means2d", "radii", "conics", "depths", "gaussian_ids", "camera_ids", "isect_ids", "flatten_ids",
+                "isect_offsets", "tiles_per_gauss"):
+        val = m(key)
+        if val is not None:
+            save["v0_" + key] = val
+    for key in ("tile_size", "tile_width", "tile_height", "width", "height"):
+        if key in meta0:
+            save["v0_" + key] = np.array(int(meta0[key]))
+    np.savez_compressed(out_path, **save)
+    print("wrote", out_path, {k: getattr(v, "shape", v) for k, v in save.items()})
+
+
+def main():
+    capture(dict(np.load(os.path.join(GOLD, "g0.npz"))), os.path.join(GOLD, "gsplat_g0.npz"))
+    try:  # the T1 scene (4 000 Gaussians, 200 x 136, D = 24) needs this repository's seeded generators
+        sys.path.insert(0, ROOT)
+        import torch
+        from gsbp_amd import synthetic as syn
+        cfg = syn.CONFIGS["T1"]
+        means, quats, scales, opac = [x.numpy() for x in syn.activate(syn.make_scene(cfg))]
+        inp = dict(means=means, quats=quats, scales=scales, opac=opac, K=syn.intrinsics(cfg).numpy(),
+                   vms=syn.make_cameras(cfg).numpy(),
+                   feats=torch.stack([syn.make_feature_map(cfg, v) for v in range(cfg.n_views)]).numpy())
+        capture(inp, os.path.join(GOLD, "gsplat_t1.npz"))
+    except ImportError as e:
+        print("T1 capture skipped:", e)
+
+
+if __name__ == "__main__":
+    main()

@@ -54,30 +54,48 @@ __global__ __launch_bounds__(WAVES * 64) void k(int groups_per_wave, int S, cons
 #pragma unroll
         for (int n = 0; n < 8; ++n)
             acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // software pipeline: A and the pixel byte of step s+2 are in flight while step s computes
-        float a0 = apool[(ks0 + 0) * 64 + lane], a1 = apool[(ks0 + 1) * 64 + lane];
-        unsigned p0 = reinterpret_cast<const unsigned char *>(kpix + ks0 + 0)[k4];
-        unsigned p1 = reinterpret_cast<const unsigned char *>(kpix + ks0 + 1)[k4];
-#pragma unroll 2
-        for (int s = 0; s < S; ++s) {
-            const int sn = min(s + 2, S - 1);
-            const float a2 = apool[(ks0 + sn) * 64 + lane];
-            const unsigned p2 = reinterpret_cast<const unsigned char *>(kpix + ks0 + sn)[k4];
-            float b[8];
-            const unsigned row = (p0 << 9) + lane_col; // 128 ch x 4 B = 512 B per pixel row
+        // A-store in blocks of 4 K-steps: apool[blk][lane] = float4 {A(4 blk + 0..3)[lane]}, kpix[blk][k4] = the four pixel
+        // bytes of this lane's k slot; PF blocks (4 PF K-steps) in flight ahead of the MFMAs
+        constexpr int PF = 3;
+        const int nblk = (S + 3) >> 2;
+        const size_t b0 = grp * (size_t)nblk;
+        const float4 *ap = reinterpret_cast<const float4 *>(apool) + b0 * 64 + lane;
+        const unsigned *pp = kpix + b0 * 4 + k4;
+        float4 aq[PF];
+        unsigned pq[PF];
 #pragma unroll
-            for (int n = 0; n < 8; ++n)
-                b[n] = MODE == 2 ? (float)(n + 1) : lds_read_b32(row + 64u * n);
-            if (MODE != 1) {
+        for (int i = 0; i < PF; ++i) {
+            aq[i] = ap[(size_t)min(i, nblk - 1) * 64];
+            pq[i] = pp[(size_t)min(i, nblk - 1) * 4];
+        }
+        for (int blk = 0; blk < nblk; ++blk) {
+            const float4 a4 = aq[0];
+            const unsigned p4 = pq[0];
+#pragma unroll
+            for (int i = 0; i + 1 < PF; ++i)
+                aq[i] = aq[i + 1], pq[i] = pq[i + 1];
+            aq[PF - 1] = ap[(size_t)min(blk + PF, nblk - 1) * 64];
+            pq[PF - 1] = pp[(size_t)min(blk + PF, nblk - 1) * 4];
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (4 * blk + t >= S) // wave-uniform: the group's last block may be short
+                    break;
+                float b[8];
+                const unsigned row = (((p4 >> (8 * t)) & 255u) << 9) + lane_col; // 128 ch x 4 B = 512 B per pixel row
 #pragma unroll
                 for (int n = 0; n < 8; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[n], acc[n], 0, 0, 0);
-            } else {
+                    b[n] = MODE == 2 ? (float)(n + 1) : lds_read_b32(row + 64u * n);
+                if (MODE != 1) {
 #pragma unroll
-                for (int n = 0; n < 8; ++n)
-                    acc[n][0] += a0 * b[n];
+                    for (int n = 0; n < 8; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b[n], acc[n], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n)
+                        acc[n][0] += av[t] * b[n];
+                }
             }
-            a0 = a1, a1 = a2, p0 = p1, p1 = p2;
         }
         if (MODE != 3) {
             // flush: record 4 * k4 + v of this group, channels 16 n + j16
@@ -133,6 +151,7 @@ static void run(const char *name, int n_cu, int gpw, int S, const float *apool, 
         cyc += h[2 * i], rt += h[2 * i + 1];
     cyc /= n_cu, rt /= n_cu;
     const double ksteps_per_simd = (double)WAVES / 4 * gpw * S;
+    (void)0;
     const double total_ksteps = (double)n_cu * WAVES * gpw * S;
     // C2 view at 128-channel chunks: 82.4 M pairs / (64 rho) K-steps x 4 chunks
     const double c2_ksteps = 82.4e6 / (64 * 0.36) * 4;
@@ -148,15 +167,16 @@ int main(int argc, char **argv)
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int n_cu = prop.multiProcessorCount;
     const int gpw_max = 64;
-    const size_t n_groups = (size_t)n_cu * 16 * gpw_max, n_ks = n_groups * S;
-    std::vector<float> ha(n_ks * 64);
-    std::vector<unsigned> hp(n_ks), hg(n_groups * 16);
+    const int nblk = (S + 3) / 4;
+    const size_t n_groups = (size_t)n_cu * 16 * gpw_max, n_ks = n_groups * nblk * 4;
+    std::vector<float> ha(n_ks * 64);                 // [group][blk][lane][t]
+    std::vector<unsigned> hp(n_ks), hg(n_groups * 16); // [group][blk][k4] = 4 pixel bytes (t = 0..3)
     srand(7);
     for (auto &v : ha)
         v = (rand() / (float)RAND_MAX) < rho ? rand() / (float)RAND_MAX : 0.f;
     for (auto &v : hp)
         v = (unsigned)(rand() & 255) | (unsigned)(rand() & 255) << 8 | (unsigned)(rand() & 255) << 16 | (unsigned)(rand() & 255) << 24;
-    const int n_rows = 1 << 20;
+    const int n_rows = 1 << 18;
     for (auto &v : hg)
         v = (unsigned)(((unsigned)rand() * 2654435761u) % n_rows);
     std::vector<float> hs(kPix * kCh);
@@ -179,7 +199,6 @@ int main(int argc, char **argv)
     printf("%d CUs, %d K-steps per group, A density %.2f\n", n_cu, S, rho);
     // correctness of the layout on one group: compare F row sums with the host for W=4 (first wave, first group)
     {
-        hipLaunchKernelGGL((k<4, 0>), dim3(1), dim3(256), (size_t)kPix * kCh * 4, 0, 1, S, apool, kpix, gids, slab, F, n_rows, clk);
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kPix * kCh * 4));
         hipLaunchKernelGGL((k<4, 0>), dim3(1), dim3(256), (size_t)kPix * kCh * 4, 0, 1, S, apool, kpix, gids, slab, F, n_rows, clk);
         CHECK(hipDeviceSynchronize());
@@ -190,9 +209,10 @@ int main(int argc, char **argv)
             for (int i = 0; i < 16; ++i)
                 for (int s = 0; s < S; ++s)
                     for (int kk = 0; kk < 4; ++kk) {
-                        const size_t ks = (size_t)w * S + s;
-                        const double a = ha[ks * 64 + kk * 16 + i];
-                        const unsigned p = (hp[ks] >> (8 * kk)) & 255u;
+                        const size_t blk = (size_t)w * nblk + s / 4;
+                        const int t = s & 3;
+                        const double a = ha[(blk * 64 + kk * 16 + i) * 4 + t];
+                        const unsigned p = (hp[blk * 4 + kk] >> (8 * t)) & 255u;
                         const unsigned row = hg[(size_t)w * 16 + i] % n_rows;
                         for (int c = 0; c < 128; ++c)
                             ref[(size_t)row * 128 + c] += a * hs[p * kCh + c];
@@ -207,6 +227,16 @@ int main(int argc, char **argv)
                 }
             }
         printf("layout check: max |err| %.3g (max |ref| %.3g) %s\n", err, mag, err <= 1e-4 * mag ? "OK" : "MISMATCH");
+        {
+            const unsigned row = hg[0] % n_rows;
+            printf("  row %u: got %g %g %g %g  want %g %g %g %g\n", row, hF[(size_t)row * 512], hF[(size_t)row * 512 + 1],
+                   hF[(size_t)row * 512 + 16], hF[(size_t)row * 512 + 127], ref[(size_t)row * 128], ref[(size_t)row * 128 + 1],
+                   ref[(size_t)row * 128 + 16], ref[(size_t)row * 128 + 127]);
+            size_t nz = 0;
+            for (size_t i = 0; i < hF.size(); ++i)
+                nz += hF[i] != 0.f;
+            printf("  non-zero elements of F: %zu (expected about %d)\n", nz, 64 * 128);
+        }
         CHECK(hipMemset(F, 0, (size_t)n_rows * 512 * 4));
     }
 #define RUN(Wv, M, name, gpw) run<Wv, M>(name, n_cu, gpw, S, apool, kpix, gids, slab, F, n_rows, clk)
