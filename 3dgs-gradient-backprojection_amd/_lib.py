@@ -43,7 +43,8 @@ class Stats(C.Structure):
                 ("reserved", C.c_uint32)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        # ("reserved" = what the last blend left in the workspace: 0 store, 1 + half-tile lists, 2 nothing, 3 + record groups)
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"} | {"blend_kind": int(self.reserved)}
 
 
 FLAG_TIGHT_BINNING = 1  # GWBP_FLAG_TIGHT_BINNING (include/gwbp.h)

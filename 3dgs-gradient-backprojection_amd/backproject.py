@@ -131,7 +131,7 @@ class ViewPipeline:
 
     def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None,
                  allow_wide: bool = True, scatter_workgroups: Optional[int] = None, side_priority: int = -1,
-                 front_priority: Optional[bool] = None, fuse_small: bool = True, allow_groups: bool = True):
+                 front_priority: Optional[bool] = None, fuse_small: bool = True, allow_groups: bool = False):
         self.dev = torch.device(device)
         self.allow_groups = bool(allow_groups)
         self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev, tight_binning=True)
@@ -204,7 +204,7 @@ class ViewPipeline:
             if e.group_capable:
                 e.set_group_scatter(groups)
             e.set_narrow_scatter(not wide)
-            e.set_front_priority(wide if self.front_priority is None else bool(self.front_priority))
+            e.set_front_priority((wide or groups) if self.front_priority is None else bool(self.front_priority))
         return "groups" if groups else "wide" if wide else "narrow"
 
     def front(self, view, means, quats, scales, opacities, d=None, scale_d=1.0):
@@ -368,6 +368,8 @@ class ViewPipeline:
         out: Dict[str, int] = {}
         for a in self.accums:
             for k, v in Engine.decode_stats(a).items():
+                if k == "blend_kind":  # a per-view fact, not a counter
+                    continue
                 out[k] = (out.get(k, 0) | v) if k == "overflow" else out.get(k, 0) + v
         return out
 
@@ -393,7 +395,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                          views: Optional[Sequence[int]] = None, view_fn=None, pipeline: bool = True,
                          return_partials: bool = False, verbose: bool = False, upsample: Optional[str] = None,
                          gather: bool = True, allow_wide: bool = True, fuse_encoder: bool = False,
-                         fuse_small: bool = True, feature_fn_stream_safe: bool = False, allow_groups: bool = True):
+                         fuse_small: bool = True, feature_fn_stream_safe: bool = False, allow_groups: bool = False):
     """Build the [N, dim_out] per-Gaussian feature field.
 
     means/quats/scales/opacities: post-activation Gaussians (backproject.py:55-57), device tensors.
@@ -414,7 +416,9 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     fuse_small: maps of at most 16 channels (after the encoder) are blended AND scattered by one kernel
     (gwbp_blend_scatter: no weight store, no scatter kernel; C5 1.96 -> 1.42 ms/view); False keeps the two-kernel form.
     allow_groups: D % 128 == 0 full-resolution maps go through the block-sparse scatter on the matrix cores
-    (GWBP_FLAG_GROUP_SCATTER, csrc/scatter_mfma.hip); False keeps the vector kernels (allow_wide picks between them).
+    (GWBP_FLAG_GROUP_SCATTER, csrc/scatter_mfma.hip).  Opt-in: measured slower than the vector kernels at one flush per
+    (Gaussian, tile) (C2: 3.7 ms alone against 3.3); False (default) keeps the vector kernels
+    (allow_wide picks between them).
     feature_fn_stream_safe: STREAM CONTRACT of feature_fn.  False (default): feature_fn runs on the caller's current stream
     and every map is handed to its consumer stream with an event -- any feature function is safe, including one that
     returns a prefetched tensor, reuses a static output buffer or replays a graph (the buffer must still not be overwritten

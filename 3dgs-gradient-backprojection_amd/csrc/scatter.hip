@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_accum_d(const u32 *__restrict__ tile_of
 
 int launch_accum_d(const Layout &L, const Ws &W, const ViewDev &V, float scale_d, float *d, hipStream_t s)
 {
-    if (L.flags & GWBP_FLAG_NARROW_SCATTER)
+    if ((L.flags & GWBP_FLAG_NARROW_SCATTER) && !(L.flags & GWBP_FLAG_GROUP_SCATTER))
         return set_error(GWBP_EINVAL, "gwbp_accumulate_d needs a blend without GWBP_FLAG_NARROW_SCATTER (no weight sums)");
     const int n_tiles = V.tile_w * V.tile_h;
     if (d && n_tiles > 0)

@@ -37,6 +37,7 @@ namespace {
 
 constexpr int kChunk = 128;
 constexpr int kThreads = 1024;
+constexpr u32 kNoPix = 320; // a "pixel" whose slab row lies past the workgroup's LDS allocation: reads as 0
 constexpr int kSlabFloats = kTilePix * kChunk; // 32768 floats = 128 KB
 constexpr size_t kLdsBytes = (size_t)kSlabFloats * 4 + 16; // slab + work counter + two item slots
 
@@ -405,8 +406,10 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
                     break;
                 const u32 n = min(64u, R.T - 64u * j);
                 EV ev;
-                ev.w = ((u32)lane < n) ? e[j].w : 0.f; // clamped loads: zero the lanes past the list
-                ev.pix = e[j].pix;
+                ev.w = ((u32)lane < n) ? e[j].w : 0.f; // clamped loads: zero the lanes past the list ...
+                // ... and point them past the slab (an out-of-range LDS read returns 0): w = 0 times the record's last pixel
+                // would turn an inf feature there into NaN (0 x inf)
+                ev.pix = ((u32)lane < n) ? e[j].pix : kNoPix;
                 wacc += ev.w;
                 run_vec(ev, n);
             }
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
                 const WPair wp = wpool[wslot(R, min(64 * j + lane, R.T - 1))];
                 EV ev;
                 ev.w = ((u32)lane < n) ? wp.w : 0.f;
-                ev.pix = wp.pix;
+                ev.pix = ((u32)lane < n) ? wp.pix : kNoPix;
                 wacc += ev.w;
                 run_vec(ev, n);
             }

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
                                                           const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
                                                           const Header *__restrict__ headers, const WPair *__restrict__ wpool,
                                                           FeatMap M, int D, float scale_f, float *F,
-                                                          u32 *__restrict__ queues, Counters *__restrict__ ctr)
+                                                          u32 *__restrict__ queues, Counters *__restrict__ ctr, int dbg)
 {
     // The group tables exist only if THIS view was blended with GWBP_FLAG_GROUP_SCATTER: refuse otherwise (F untouched,
     // overflow bit 2 raised), like k_scatter_wide
@@ -312,7 +312,9 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
     extern __shared__ __attribute__((aligned(16))) float lds[];
     u32 *s_next = reinterpret_cast<u32 *>(lds + kSlabFloats);
     u32 *s_item = s_next + 1; // two slots: iteration k reads [k & 1], thread 0 fills [(k + 1) & 1] meanwhile
-    u32 *s_bad = s_next + 3;  // the slab holds a non-finite value
+    u32 *s_bad = s_next + 3;  // [k & 1]: item k's slab holds a non-finite value (two flags: thread 0 clears the NEXT item's
+                              // flag while the current item runs -- clearing the current one would race with the staging
+                              // waves that are already raising it)
     const float *__restrict__ feats = M.p;
 
     // persistent workgroups, per-XCD-class queues: as k_scatter_full
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
     const int j16 = lane & 15, k4 = lane >> 4;
     const u32 lane_col = (u32)j16 * 4u;
     if (threadIdx.x == 0)
-        s_item[0] = atomicAdd(queue, 1u);
+        s_item[0] = atomicAdd(queue, 1u), s_bad[0] = 0u, s_bad[1] = 0u;
     __syncthreads();
     for (u32 k = 0;; ++k) {
     const u32 item = uniform(s_item[k & 1u]);
@@ -337,11 +339,11 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
     const int tx = tile % V.tile_w, ty = tile / V.tile_w;
     const int c0 = chunk * kChunk;
     if (threadIdx.x == 0)
-        *s_next = 0, *s_bad = 0;
+        *s_next = 0, s_bad[(k + 1u) & 1u] = 0u;
     u32 nxt = 0;
     if (threadIdx.x == 0)
         nxt = atomicAdd(queue, 1u); // claim the next item; the value is only needed after the slab is staged
-    if (n_grp != 0) {
+    if (n_grp != 0 && !(dbg & 4)) {
         // stage the 256 px x 128 ch slab: 32 float4 per pixel row, eight 16-B loads per thread in flight
         constexpr int vpr = kChunk >> 2;
         constexpr int kIt = kTilePix * vpr / kThreads; // 8
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
             bad |= !(z == 0.f);
         }
         if (__ballot(bad) != 0ull && lane == 0)
-            atomicOr(s_bad, 1u);
+            atomicOr(&s_bad[k & 1u], 1u);
     }
     if (threadIdx.x == 0)
         s_item[(k + 1u) & 1u] = nxt;
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
         return uniform(h);
     };
 
-    if (n_grp != 0 && uniform(*s_bad) == 0u) {
+    if (n_grp != 0 && uniform(s_bad[k & 1u]) == 0u) {
         // ---- block-sparse path ---------------------------------------------------------------------------------------
         // Operand stream: slot u of sl[] holds block (u mod kPF) of the current group and is refilled (block + kPF) right
         // after its block has been consumed -- never rotated (a register move would wait for every load in flight).
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
                 for (int u = 0; u < kPF; ++u) {
                     const float4 a4 = sl[u].a;
                     const u32 p4 = sl[u].p;
-                    if (blk0 + u < cur_blk) { // wave-uniform; no memory operation inside
+                    if (blk0 + u < cur_blk && !(dbg & 2)) { // wave-uniform; no memory operation inside
                         const float av[4] = {a4.x, a4.y, a4.z, a4.w};
                         // all four K-steps of a block run: k_pack zero-fills the K-steps past the group's last one
 #pragma unroll
@@ -462,9 +464,15 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 float *Fg = F + (int64_t)gv[v] * D + c0 + j16;
+                if (!(dbg & 1)) {
 #pragma unroll
-                for (int n = 0; n < 8; ++n)
-                    atomicAdd(Fg + 16 * n, acc[n][v] * scale_f);
+                    for (int n = 0; n < 8; ++n)
+                        atomicAdd(Fg + 16 * n, acc[n][v] * scale_f);
+                } else { // ablation (PROFILE build): same VMEM count, no atomics
+#pragma unroll
+                    for (int n = 0; n < 8; ++n)
+                        __builtin_nontemporal_store(acc[n][v] * scale_f, Fg + 16 * n);
+                }
             }
             order_fence();
         };
@@ -542,7 +550,7 @@ int launch_scatter_mfma(const Layout &L, const Ws &W, const ViewDev &V, const Fe
     u32 *queues = W.shards + kShards * 16;
     hipLaunchKernelGGL(k_scatter_mfma, dim3(grid), dim3(kThreads), kLdsBytes, s, V, D / kChunk, W.tile_grp, W.grp_info,
                        W.grp_gid, W.apool, W.kpix, W.tile_offsets, W.hdr_count, W.headers, W.wpool, M, D, scale_f, F, queues,
-                       W.counters);
+                       W.counters, profile_knob("GWBP_ABLATE"));
     return check_hip(hipGetLastError(), "scatter_mfma launch");
 }
 

@@ -27,6 +27,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gwbp_dev.h"
 
 namespace gwbp {
@@ -241,17 +243,21 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         r.row = uniform(hp->row);
         return r;
     };
-    auto prefetch = [&](const Visit &R, Pre &x) __attribute__((always_inline)) { // exactly kLoads VMEM loads
+    // exactly 2 (top pass) / kLoads (bottom pass) VMEM loads: the top pass never resumes a record, so it issues no carry
+    // loads at all (they were ~1.8 M x 4 L2 requests per view that fetched nothing)
+    auto prefetch = [&](const Visit &R, Pre &x, auto bottom) __attribute__((always_inline)) {
         const u32 last = R.n - 1;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             issue_e(x.e[j], wpool + (R.off + min((u32)(64 * j + lane), last)));
-        // carry dwords of this lane (top pass and non-spanning records: row 0, value ignored)
-        const float *cr = carry + (size_t)((phase && R.span) ? R.row : 0u) * kWide + lane;
-        issue_c<0>(x.c[0], cr);
-        issue_c<256>(x.c[1], cr);
-        issue_c<512>(x.c[2], cr);
-        issue_c<768>(x.c[3], cr);
+        if constexpr (decltype(bottom)::value) {
+            // carry dwords of this lane (non-spanning records: row 0, value ignored -- the count must stay exact)
+            const float *cr = carry + (size_t)(R.span ? R.row : 0u) * kWide + lane;
+            issue_c<0>(x.c[0], cr);
+            issue_c<256>(x.c[1], cr);
+            issue_c<512>(x.c[2], cr);
+            issue_c<768>(x.c[3], cr);
+        }
     };
 
     float4 acc;
@@ -305,8 +311,9 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
                     break;
                 const u32 n = min(64u, R.n - 64u * j);
                 EV ev;
-                ev.w = ((u32)lane < n) ? x.e[j].w : 0.f; // clamped loads / the other half's entries: zero them
-                ev.pix = x.e[j].pix;
+                ev.w = ((u32)lane < n) ? x.e[j].w : 0.f; // clamped loads / the other half's entries: zero them ...
+                // ... and send them past the slab (out-of-range LDS reads return 0): 0 x inf at the record's last pixel is NaN
+                ev.pix = ((u32)lane < n) ? x.e[j].pix : 640u;
                 run_vec(ev, n);
             }
         }
@@ -331,44 +338,52 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         }
     };
 
-    // visit pipeline: header scalar loads two visits ahead, entry + carry loads one visit ahead (A/B buffers)
-    Pre pA = {{{0.f, 0u}, {0.f, 0u}}, {0.f, 0.f, 0.f, 0.f}}, pB = pA;
-    u32 h = claim();
-    if (h < nh) {
-        Visit Rcur = load_visit(h);
-        prefetch(Rcur, pA);
-        h = claim();
-        bool vnxt = h < nh;
-        Visit Rnxt = load_visit(h);
+    // visit pipeline: header scalar loads two visits ahead, entry (+ carry) loads one visit ahead (A/B buffers); one copy
+    // of the loop per pass, because the number of loads per visit -- hence the counted wait -- differs
+    auto visits = [&](auto bottom) __attribute__((always_inline)) {
+        constexpr int kL = decltype(bottom)::value ? kLoads : 2;
+        Pre pA = {{{0.f, 0u}, {0.f, 0u}}, {0.f, 0.f, 0.f, 0.f}}, pB = pA;
+        u32 h = claim();
+        if (h < nh) {
+            Visit Rcur = load_visit(h);
+            prefetch(Rcur, pA, bottom);
+            h = claim();
+            bool vnxt = h < nh;
+            Visit Rnxt = load_visit(h);
 
-        // peeled first visit: only loads(1) are guaranteed younger than loads(0)
-        prefetch(Rnxt, pB);
-        h = claim();
-        bool vnn = h < nh;
-        Visit Rnn = load_visit(h);
-        wait_pre<kLoads>(pA);
-        process(Rcur, pA);
-        while (vnxt) {
-            // odd: current visit's data in pB; next loads into pA
-            Rcur = Rnxt, Rnxt = Rnn, vnxt = vnn;
-            prefetch(Rnxt, pA);
+            // peeled first visit: only loads(1) are guaranteed younger than loads(0)
+            prefetch(Rnxt, pB, bottom);
             h = claim();
-            vnn = h < nh;
-            Rnn = load_visit(h);
-            wait_pre<kLoads + kFlush>(pB);
-            process(Rcur, pB);
-            if (!vnxt)
-                break;
-            // even: current in pA; next into pB
-            Rcur = Rnxt, Rnxt = Rnn, vnxt = vnn;
-            prefetch(Rnxt, pB);
-            h = claim();
-            vnn = h < nh;
-            Rnn = load_visit(h);
-            wait_pre<kLoads + kFlush>(pA);
+            bool vnn = h < nh;
+            Visit Rnn = load_visit(h);
+            wait_pre<kL>(pA);
             process(Rcur, pA);
+            while (vnxt) {
+                // odd: current visit's data in pB; next loads into pA
+                Rcur = Rnxt, Rnxt = Rnn, vnxt = vnn;
+                prefetch(Rnxt, pA, bottom);
+                h = claim();
+                vnn = h < nh;
+                Rnn = load_visit(h);
+                wait_pre<kL + kFlush>(pB);
+                process(Rcur, pB);
+                if (!vnxt)
+                    break;
+                // even: current in pA; next into pB
+                Rcur = Rnxt, Rnxt = Rnn, vnxt = vnn;
+                prefetch(Rnxt, pB, bottom);
+                h = claim();
+                vnn = h < nh;
+                Rnn = load_visit(h);
+                wait_pre<kL + kFlush>(pA);
+                process(Rcur, pA);
+            }
         }
-    }
+    };
+    if (phase)
+        visits(std::true_type{});
+    else
+        visits(std::false_type{});
     // Drain: (1) the last prefetch still targets pA/pB's registers, (2) the carry rows parked in the top pass must be
     // in L2 before any wave of the bottom pass loads them, (3) the slab is about to be overwritten.
     GWBP_STAMP(ts2);

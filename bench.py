@@ -38,8 +38,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=8, help="views of the workload the CPU baseline is timed on")
     ap.add_argument("--scatter", choices=("auto", "groups", "wide", "narrow"), default="auto",
-                    help="scatter kernel: groups = block-sparse on the matrix cores (D %% 128 == 0), wide / narrow = the 256- / "
-                         "128-channel vector kernels; auto = groups when D %% 128 == 0, else chosen from the warm-up views' counters")
+                    help="scatter kernel: groups = block-sparse on the matrix cores (D %% 128 == 0; opt-in, measured slower), "
+                         "wide / narrow = the 256- / 128-channel vector kernels; auto = wide or narrow from the warm-up views' counters")
     ap.add_argument("--pipe-wgs", type=int, default=None, help="persistent scatter workgroups (tuning)")
     ap.add_argument("--side-prio", type=int, default=-1, help="HIP priority of the front stage's stream")
     ap.add_argument("--front-prio", choices=("auto", "on", "off"), default="auto",
@@ -124,7 +124,7 @@ def main():
     # feature-map pool, generated on device (seeded), L2-normalised over channels like backproject.py:109
     pool = [syn.make_feature_map(cfg, 1000 * rank + i, device=dev) for i in range(args.pool)]
     tight = not args.exact_binning
-    use_groups = args.scatter in ("auto", "groups") and D % 128 == 0
+    use_groups = args.scatter == "groups" and D % 128 == 0
     eng = gsbp_amd.Engine(N, W, H, device=dev, tight_binning=tight, group_scatter=use_groups)
     F, d, F_store = gsbp_amd.backproject.alloc_accumulators(N, D, dev, world)
     views = [eng.view(vms[v], K, W, H) for v in my_views]

@@ -292,3 +292,42 @@ def test_dino_width_1024_nearest_64x64_mean_reduction(dev, orc):
     assert rel_row_err(F[sel_t].cpu().numpy(), Fr) <= 1e-4
     assert rel_row_err(d[sel_t].cpu().numpy()[:, None], dr[:, None]) <= 1e-4
     assert np.abs(out[sel_t].cpu().numpy() - orc.finalize(Fr, dr)).max() <= 1e-4
+
+
+def test_wide_forward_render_c2_band_vs_oracle(orc, c2, dev):
+    """gwbp_render (k_render_rows) at C2 geometry with a 512-wide colour table -- the feature render of the reference's
+    consumers (segment.py:209-220: rasterization(..., features[N,512], ...)) -- against the CPU oracle on a 64-row pixel
+    band: out[p, :] = sum_g w_g(p) colors[g, :] with the ORACLE's own blend (its (Gaussian, pixel, weight) list of the
+    view), accumulated in float64."""
+    cfg, eng, g, vms, K = c2
+    D = 512
+    gen = torch.Generator().manual_seed(77)
+    colors = torch.randn(cfg.n_gaussians, D, generator=gen)
+    view = eng.view(vms[0], K, cfg.width, cfg.height)
+    eng.project(view, *g)
+    eng.bin_sort(view)
+    eng.blend_weights(view)
+    out = eng.render(view, colors.to(dev))
+    assert eng.stats()["overflow"] == 0 and tuple(out.shape) == (cfg.height, cfg.width, D)
+    y0, rows = 500, 64
+    band = out[y0:y0 + rows].cpu().double().reshape(-1, D)
+    h = [t.cpu().numpy() for t in g]
+    proj = orc.project(h[0], h[1], h[2], vms[0].numpy(), K.numpy(), cfg.width, cfg.height)
+    bins = orc.bin_sort(proj, cfg.width, cfg.height)
+    gid, pix, w, _ = orc.blend_pairs(proj, bins, h[3], cfg.width, cfg.height)
+    sel = (pix >= y0 * cfg.width) & (pix < (y0 + rows) * cfg.width)
+    gid_b = torch.from_numpy(gid[sel].astype(np.int64))
+    pix_b = torch.from_numpy((pix[sel] - y0 * cfg.width).astype(np.int64))
+    w_b = torch.from_numpy(w[sel].astype(np.float64))
+    assert len(gid_b) > 1e6
+    ref = torch.zeros(rows * cfg.width, D, dtype=torch.float64)
+    cd = colors.double()
+    for s in range(0, len(gid_b), 1 << 18):  # 256 K pairs x 512 doubles = 1 GB of temporaries per slice
+        e = s + (1 << 18)
+        ref.index_add_(0, pix_b[s:e], w_b[s:e, None] * cd[gid_b[s:e]])
+    scale = float(ref.abs().max())
+    assert float((band - ref).abs().max()) <= 2e-6 * scale * 8  # ~50 terms per pixel, fp32 accumulators
+    # pixels nobody covers render exactly zero
+    empty = torch.ones(rows * cfg.width, dtype=torch.bool)
+    empty[pix_b] = False
+    assert float(band[empty].abs().max() if empty.any() else 0.0) == 0.0

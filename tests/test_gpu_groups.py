@@ -33,7 +33,7 @@ def test_group_scatter_matches_oracle_and_vector_kernel(orc, dev, name, D):
     eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, group_scatter=True)
     view = _blend(eng, d, cfg, 0)
     st = eng.stats()
-    assert st["overflow"] == 0 and st["reserved"] == 3  # store + record groups
+    assert st["overflow"] == 0 and st["blend_kind"] == 3  # store + record groups
     F = torch.zeros(cfg.n_gaussians, D, device=dev)
     dd = torch.zeros(cfg.n_gaussians, device=dev)
     eng.scatter(view, feats.to(dev), F, dd)
@@ -58,11 +58,12 @@ def test_group_scatter_matches_oracle_and_vector_kernel(orc, dev, name, D):
     assert rel_row_err(2.0 * F3.cpu().numpy(), F.cpu().numpy().astype(np.float64)) <= 2e-6
 
 
-def test_group_scatter_keeps_nan_where_the_reference_has_it(dev):
+def test_non_finite_features_reach_exactly_the_gaussians_that_touch_them(dev):
     """feats / feats.norm() of an all-zero pixel is NaN in the reference (backproject.py:109): it reaches exactly the
     Gaussians with weight on that pixel.  A dense operand table multiplies every pixel of the group's union by every record
-    (0 x NaN = NaN), so tiles whose staged pixels are not all finite take the exact sparse path: the NaN pattern and the
-    finite rows must equal the vector kernel's."""
+    (0 x NaN = NaN), so tiles whose staged pixels are not all finite take the exact sparse path; the vector kernels must
+    not multiply a zero-weight padding lane by a non-finite pixel either (0 x inf).  Expectation: the plain sum over the
+    view's (Gaussian, pixel, weight) triples in float64 -- NaN / +-inf patterns must agree exactly, finite values closely."""
     cfg, sc = scene_np("T1")
     d = to_dev(sc, dev)
     D = 128
@@ -70,18 +71,38 @@ def test_group_scatter_keeps_nan_where_the_reference_has_it(dev):
     feats[10, 20, :] = float("nan")
     feats[50, 100, 7] = float("inf")
     feats[100, 150, 64:] = float("-inf")
+    feats[0, 0, 3] = float("nan")      # the first pixel of tile 0
+    feats[31, 47, :] = float("inf")    # the last pixel of a tile
     eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, group_scatter=True)
     view = _blend(eng, d, cfg, 0)
-    F = torch.zeros(cfg.n_gaussians, D, device=dev)
-    eng.scatter(view, feats.to(dev), F, None)
-    eng.set_group_scatter(False)
-    F2 = torch.zeros_like(F)
-    eng.scatter(view, feats.to(dev), F2, None)
-    a, b = F.cpu(), F2.cpu()
-    assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.isinf(a), torch.isinf(b))
-    assert int(torch.isnan(a).any(dim=1).sum()) > 0  # the poisoned pixels are covered by some Gaussian
-    fin = torch.isfinite(a)
-    assert float(((a - b)[fin]).abs().max()) <= 1e-5 * float(b[fin].abs().max())
+    gid, pix, w = [t.cpu().numpy() for t in eng.dump_pairs(view)]
+    want = np.zeros((cfg.n_gaussians, D))
+    with np.errstate(invalid="ignore"):
+        np.add.at(want, gid, w[:, None].astype(np.float64) * feats.reshape(-1, D).numpy().astype(np.float64)[pix])
+    assert np.isnan(want).any() and np.isinf(want).any()
+    got = {}
+    for name, setup in (("groups", lambda: eng.set_group_scatter(True)),
+                        ("narrow", lambda: (eng.set_group_scatter(False), eng.set_narrow_scatter(True))),):
+        setup()
+        F = torch.zeros(cfg.n_gaussians, D, device=dev)
+        eng.scatter(view, feats.to(dev), F, None)
+        got[name] = F.cpu().numpy()
+    # the 256-channel vector kernel on the same view (its own blend: it needs the half-tile lists)
+    D2 = 256
+    feats2 = torch.cat([feats, feats], dim=2).contiguous()
+    wide = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev)
+    wide.set_narrow_scatter(False)
+    view2 = _blend(wide, d, cfg, 0)
+    F = torch.zeros(cfg.n_gaussians, D2, device=dev)
+    wide.scatter(view2, feats2.to(dev), F, None)
+    got["wide"] = F.cpu().numpy()[:, :D]
+    both = F.cpu().numpy()  # (the two identical halves differ only by the order of the flush atomics)
+    assert np.array_equal(np.isnan(both[:, :D]), np.isnan(both[:, D:]))
+    for name, g in got.items():
+        assert np.array_equal(np.isnan(g), np.isnan(want)), name
+        assert np.array_equal(np.isposinf(g), np.isposinf(want)) and np.array_equal(np.isneginf(g), np.isneginf(want)), name
+        fin = np.isfinite(want)
+        assert np.abs(g[fin] - want[fin]).max() <= 1e-5 * np.abs(want[fin]).max(), name
 
 
 def test_group_tables_overflow_is_flagged_and_grown(dev):
@@ -93,7 +114,7 @@ def test_group_tables_overflow_is_flagged_and_grown(dev):
     vms = syn.make_cameras(cfg).to(dev)
     maps = [torch.randn(cfg.height, cfg.width, D, generator=torch.Generator().manual_seed(v)).to(dev) for v in range(4)]
     args = (d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"], cfg.width, cfg.height, lambda v: maps[v], D)
-    ref, Fr, dr, st_r = gsbp_amd.create_feature_field(*args, return_partials=True)
+    ref, Fr, dr, st_r = gsbp_amd.create_feature_field(*args, return_partials=True, allow_groups=True)
     assert st_r["overflow"] == 0
     probe = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, group_scatter=True)
     view = _blend(probe, d, cfg, 0)
@@ -117,7 +138,7 @@ def test_pipelined_driver_uses_groups_and_matches_vector_kernels(dev):
     maps = [torch.randn(cfg.height, cfg.width, D, generator=torch.Generator().manual_seed(v)).to(dev) for v in range(5)]
     args = (d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"], cfg.width, cfg.height, lambda v: maps[v], D)
     res = []
-    for kw in (dict(), dict(allow_groups=False), dict(allow_groups=False, allow_wide=False), dict(pipeline=False)):
+    for kw in (dict(allow_groups=True), dict(), dict(allow_wide=False), dict(pipeline=False, allow_groups=True)):
         out, F, dd, st = gsbp_amd.create_feature_field(*args, return_partials=True, **kw)
         assert st["overflow"] == 0
         res.append((F.cpu().numpy().astype(np.float64), dd.cpu().numpy(), st["n_pairs"]))
