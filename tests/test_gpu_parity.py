@@ -3,6 +3,8 @@
 Bars: integer/index outputs and per-pair weights bit-exact; fp32 sums within 1e-4 relative (north_star),
 measured per Gaussian row as in SURVEY.md 8(d).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
