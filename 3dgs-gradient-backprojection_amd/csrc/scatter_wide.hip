@@ -19,11 +19,14 @@
 // atomic wave-instructions with no cross-lane transpose.  Staging loads are therefore dword loads (256 B per
 // wave-instruction, coalesced) feeding one ds_write_b128 per (pixel, lane).
 //
-// Every VMEM instruction of a visit is unconditional (6 loads, 4 flush operations), so the counted s_waitcnt in front
-// of a visit's entries is exact: vmcnt(10) (scatter_full.hip explains why it must be).  The denominator d is not
-// accumulated here: k_blend leaves every record's weight sum in its header and k_accum_d (scatter.hip) adds them --
-// a fifth, conditional operation per visit would break the count, and a stand-in for it cost more than the kernel
-// saved (in-kernel d with a stand-in store: 4.51 ms/view in the pipeline; k_accum_d: 4.25).  experiments/r1_scatter_wide/README.md has the measurements and the pitfalls of the first attempt.
+// Every VMEM instruction of a visit is unconditional WITHIN a pass, so the counted s_waitcnt in front of a visit's entries is
+// exact (scatter_full.hip explains why it must be): the top pass issues 2 entry loads + 4 flush operations per visit
+// (vmcnt(6)), the bottom pass 2 entry + 4 carry loads + 4 flush operations (vmcnt(10)); the visit loop is instantiated once
+// per pass.  The denominator d is not accumulated here: the blend adds every record's weight sum to d itself
+// (gwbp_blend_weights_d: one 4-B atomic per record on the front's stream), or k_accum_d (scatter.hip) does from the headers
+// when gwbp_scatter is handed d -- a fifth, conditional operation per visit would break the count, and a stand-in for it
+// cost more than the kernel saved (in-kernel d with a stand-in store: 4.51 ms/view in the pipeline; separate: 4.25).
+// experiments/r1_scatter_wide/README.md has the measurements and the pitfalls of the first attempt.
 
 #include <stdlib.h>
 

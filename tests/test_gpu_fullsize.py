@@ -133,7 +133,7 @@ def _spy_pipeline(monkeypatch):
 def test_c2_d512_pipelined_wide_path_against_oracle(dev, orc, monkeypatch):
     """What bench.py times, checked at its own size: C2 (1M Gaussians, 1600x1060), D = 512 (two 256-channel chunks),
     three views through create_feature_field(pipeline=True): ViewPipeline on two streams, k_scatter_wide, the
-    denominators added by k_accum_d on the side stream, raised front priority -- against the CPU oracle."""
+    denominators added by the blend itself on the side stream (gwbp_blend_weights_d), raised front priority -- against the CPU oracle."""
     cfg = syn.CONFIGS["C2"]
     D, V = cfg.feat_dim, 3
     g_cpu = syn.activate(syn.make_scene(cfg))
