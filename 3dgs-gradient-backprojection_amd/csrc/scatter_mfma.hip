@@ -39,8 +39,12 @@ namespace {
 constexpr int kMaxSeg = 4096; // records of one tile sorted / grouped together (longer lists: several segments)
 constexpr int kChunk = 128;
 constexpr int kThreads = 1024;
-constexpr int kSlabFloats = kTilePix * kChunk;             // 32768 floats = 128 KB
-constexpr size_t kLdsBytes = (size_t)kSlabFloats * 4 + 32; // slab + work counter + two item slots + non-finite flag
+// Slab rows are PADDED by 16 floats (576 B instead of 512): a K-step reads four pixel rows at once (one per 16 lanes), and
+// with a 512-B pitch all four start on the same LDS bank (4-way conflict on every B read: SQ_LDS_BANK_CONFLICT was 2.2e8 of
+// 4.8e8 LDS cycles per C2 view); at 576 B consecutive pixels are 16 banks apart.  147 KB of the CU's 160 KB.
+constexpr int kRowFloats = kChunk + 16;
+constexpr int kSlabFloats = kTilePix * kRowFloats;         // 36864 floats = 144 KB
+constexpr size_t kLdsBytes = (size_t)kSlabFloats * 4 + 32; // slab + work counter + two item slots + non-finite flags
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ u32 shfl_xor_u(u32 v, int m) { return (u32)__shfl_xor((int)v, m, 64); }
@@ -282,7 +286,7 @@ __device__ __forceinline__ float lds_read_b32(u32 a)
 #endif
 }
 
-constexpr int kPF = 4; // blocks (of 4 K-steps) in flight ahead of the MFMAs
+constexpr int kPF = 3; // blocks (of 4 K-steps) in flight ahead of the MFMAs
 
 // compiler-only fence: memory operations are neither moved across it nor merged over it (no instruction is emitted)
 __device__ __forceinline__ void order_fence() { asm volatile("" ::: "memory"); }
@@ -300,8 +304,14 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
                                                           const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
                                                           const Header *__restrict__ headers, const WPair *__restrict__ wpool,
                                                           FeatMap M, int D, float scale_f, float *F,
-                                                          u32 *__restrict__ queues, Counters *__restrict__ ctr, int dbg)
+                                                          u32 *__restrict__ queues, Counters *__restrict__ ctr, int dbg_arg)
 {
+#ifdef GWBP_PROFILE
+    const int dbg = dbg_arg; // ablation bits (PROFILE build only): 1 plain stores for the atomics, 2 no MFMA / LDS work, 4 no staging
+#else
+    constexpr int dbg = 0;   // the product kernel must not even contain the branches: they would break the counted waits
+    (void)dbg_arg;
+#endif
     // The group tables exist only if THIS view was blended with GWBP_FLAG_GROUP_SCATTER: refuse otherwise (F untouched,
     // overflow bit 2 raised), like k_scatter_wide
     if (uniform(ctr->blend_kind) != kBlendGroups) {
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
         for (int it = 0; it < kIt; ++it) {
             const int idx = it * kThreads + threadIdx.x;
             const int p = idx / vpr, v = idx - p * vpr;
-            *reinterpret_cast<float4 *>(lds + p * kChunk + 4 * v) = vals[it];
+            *reinterpret_cast<float4 *>(lds + p * kRowFloats + 4 * v) = vals[it];
             // x - x is 0 for every finite x and NaN for +-inf / NaN
             const float z = (vals[it].x - vals[it].x) + (vals[it].y - vals[it].y) + (vals[it].z - vals[it].z) +
                             (vals[it].w - vals[it].w);
@@ -386,45 +396,69 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
 
     if (n_grp != 0 && uniform(s_bad[k & 1u]) == 0u) {
         // ---- block-sparse path ---------------------------------------------------------------------------------------
-        // Operand stream: slot u of sl[] holds block (u mod kPF) of the current group and is refilled (block + kPF) right
-        // after its block has been consumed -- never rotated (a register move would wait for every load in flight).
+        // The operand stream of a wave is SEAMLESS across its groups.  Slot u of sl[] holds block (u mod kPF) of the current
+        // group and is refilled, right after its block has been consumed, with the block kPF further on -- which in a group's
+        // LAST round is block u of the NEXT group (whose header was fetched two groups ago): a group boundary issues no
+        // stream load, nothing waits for a cold first block, and no slot is written while an older load to it is in flight.
+        // Slots are never rotated (a register move would wait for every load in flight).
         // vmcnt retires in order and an atomic stays counted for ~3000 cycles under load (scatter_full.hip), so the waits
-        // for the stream loads must be COUNTED: the code is shaped so that hipcc's own wait insertion can count exactly --
-        // every sub-step issues exactly two loads (past the group's last block: clamped re-reads, arithmetic skipped),
-        // a group boundary issues [gid load] [2 kPF stream loads of the next group] [32 atomics of this group], always,
-        // and the first group of an item is peeled so that the loop is only ever entered behind a boundary.
+        // for the stream loads must be COUNTED; the code is shaped so that hipcc's own wait insertion counts exactly:
+        // every sub-step issues exactly two loads (arithmetic of the blocks past the group's last one is skipped, the
+        // loads are not), a boundary issues [gid of the next group] [32 atomics] (+ a scalar header load), always; a
+        // group's first round is a separate copy of the code (its loads have a boundary behind them), and so is the first
+        // group of an item (they do not).
         Slot sl[kPF];
-        u32 h = claim();
-        bool have = h < n_grp;
-        u32 g = g_base + min(h, n_grp - 1);
-        u32 blk_off = uniform(grp_info[g].blk_off), n_blk = max((uniform(grp_info[g].n_ks) + 3u) >> 2, 1u);
-        uint4 gid4 = reinterpret_cast<const uint4 *>(grp_gid + (size_t)g * kGrp)[k4];
-        const float4 *ap = apool + (size_t)blk_off * 64 + lane;
-        const u32 *pp = kpix + (size_t)blk_off * 4 + k4;
+        // group headers are fetched TWO groups ahead with SCALAR loads (wave-uniform address): they are consumed at a
+        // boundary, where the K loop's LDS reads have long drained and lgkmcnt(0) costs nothing -- a vector load would have
+        // to be awaited with vmcnt, and hipcc's count for it collapses across the rounds loop (it emitted vmcnt(2), i.e. a
+        // wait for the next group's first blocks, at every boundary)
+        auto fetch_info = [&](u32 gg) __attribute__((always_inline)) -> uint2 {
+            const GrpInfo gi = grp_info[gg];
+            return make_uint2(gi.blk_off, gi.n_ks);
+        };
+        auto claim_group = [&](bool &ok) __attribute__((always_inline)) -> u32 {
+            const u32 hh = claim();
+            ok = hh < n_grp;
+            return g_base + min(hh, n_grp - 1); // past the end: the last group again (loaded, never computed or flushed)
+        };
+        bool have, have2, have3;
+        const u32 g1 = claim_group(have);
+        const uint2 i1 = fetch_info(g1);
+        const u32 g2f = claim_group(have2);
+        const uint2 i2 = fetch_info(g2f);
+        u32 g3 = claim_group(have3);
+        uint2 info3 = fetch_info(g3);
+        u32 n_blk = max((uniform(i1.y) + 3u) >> 2, 1u), n_blk2 = max((uniform(i2.y) + 3u) >> 2, 1u);
+        const float4 *ap = apool + (size_t)uniform(i1.x) * 64 + lane, *ap2 = apool + (size_t)uniform(i2.x) * 64 + lane;
+        const u32 *pp = kpix + (size_t)uniform(i1.x) * 4 + k4, *pp2 = kpix + (size_t)uniform(i2.x) * 4 + k4;
+        uint4 gid4 = reinterpret_cast<const uint4 *>(grp_gid + (size_t)g1 * kGrp)[k4];
+        u32 g2 = g2f;
 #pragma unroll
         for (int u = 0; u < kPF; ++u) {
-            const u32 b = min((u32)u, n_blk - 1);
-            sl[u].a = ap[(size_t)b * 64], sl[u].p = pp[(size_t)b * 4];
+            const u32 bb = min((u32)u, n_blk - 1);
+            sl[u].a = ap[(size_t)bb * 64], sl[u].p = pp[(size_t)bb * 4];
         }
         order_fence();
         auto group = [&]() __attribute__((always_inline)) {
             const u32 cur_blk = n_blk;
-            const uint4 cur_gid = gid4;
             f32x4_t acc[8];
 #pragma unroll
             for (int n = 0; n < 8; ++n)
                 acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             auto round = [&](u32 blk0) __attribute__((always_inline)) {
+                const bool last_round = blk0 + kPF >= cur_blk; // wave-uniform
 #pragma unroll
                 for (int u = 0; u < kPF; ++u) {
                     const float4 a4 = sl[u].a;
                     const u32 p4 = sl[u].p;
                     if (blk0 + u < cur_blk && !(dbg & 2)) { // wave-uniform; no memory operation inside
                         const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-                        // all four K-steps of a block run: k_pack zero-fills the K-steps past the group's last one
+                        // all four K-steps of a block run: k_pack zero-fills the K-steps past the group's last one.
+                        // (Issuing the eight B reads of K-step t + 1 ahead of the MFMAs of K-step t -- two register sets,
+                        // scheduling barriers -- was measured SLOWER: 3.91 against 3.78 ms per C2 view, 128 VGPRs + spills.)
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
-                            const u32 row = (((p4 >> (8 * t)) & 255u) << 9) + lane_col; // 128 ch x 4 B per pixel row
+                            const u32 row = ((p4 >> (8 * t)) & 255u) * (u32)(kRowFloats * 4) + lane_col; // padded pixel row
                             float b[8];
 #pragma unroll
                             for (int n = 0; n < 8; ++n)
@@ -434,33 +468,24 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
                                 acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b[n], acc[n], 0, 0, 0);
                         }
                     }
-                    const u32 nb = min(blk0 + u + kPF, cur_blk - 1);
-                    sl[u].a = ap[(size_t)nb * 64], sl[u].p = pp[(size_t)nb * 4];
+                    // refill: the block kPF further on -- of this group, or block u of the next one
+                    const float4 *rp = last_round ? ap2 + (size_t)min((u32)u, n_blk2 - 1) * 64
+                                                  : ap + (size_t)min(blk0 + u + kPF, cur_blk - 1) * 64;
+                    const u32 *rq = last_round ? pp2 + (size_t)min((u32)u, n_blk2 - 1) * 4
+                                               : pp + (size_t)min(blk0 + u + kPF, cur_blk - 1) * 4;
+                    sl[u].a = *rp, sl[u].p = *rq;
                     order_fence(); // the refill is issued HERE (hipcc would otherwise sink or hoist it across blocks)
                 }
             };
-            // the first round is peeled: behind a boundary the 32 atomics are younger than the stream loads it waits for
-            // (wait count 2 (kPF - 1) + 32), in the later rounds only the refills are (2 (kPF - 1))
             round(0);
             for (u32 blk0 = kPF; blk0 < cur_blk; blk0 += kPF)
                 round(blk0);
-            // group boundary: [gid load] [stream loads of the next group] [this group's 32 atomics].  Exactly 32 atomics,
-            // unconditional: empty slots of a tile's last group carry a real Gaussian id and an all-zero operand row (+0).
-            h = claim();
-            have = h < n_grp;
-            g = g_base + min(h, n_grp - 1);
-            blk_off = uniform(grp_info[g].blk_off), n_blk = max((uniform(grp_info[g].n_ks) + 3u) >> 2, 1u);
-            gid4 = reinterpret_cast<const uint4 *>(grp_gid + (size_t)g * kGrp)[k4];
-            ap = apool + (size_t)blk_off * 64 + lane;
-            pp = kpix + (size_t)blk_off * 4 + k4;
-#pragma unroll
-            for (int u = 0; u < kPF; ++u) {
-                const u32 b = min((u32)u, n_blk - 1);
-                sl[u].a = ap[(size_t)b * 64], sl[u].p = pp[(size_t)b * 4];
-            }
-            order_fence(); // the atomics stay BEHIND the next group's loads
-            // flush: D register v of block n = record 4 k4 + v, channel 16 n + j16 -> 4 records x 64 contiguous bytes
-            const u32 gv[4] = {cur_gid.x, cur_gid.y, cur_gid.z, cur_gid.w};
+            // boundary: [32 atomics of this group] [gid of the next group] (+ a scalar header load), always.  Exactly 32
+            // atomics, unconditional: empty slots of a tile's last group carry a real Gaussian id and an all-zero operand
+            // row (they add +0).  D register v of block n = record 4 k4 + v, channel 16 n + j16 -> 4 records x 64
+            // contiguous bytes per instruction.
+            order_fence();
+            const u32 gv[4] = {gid4.x, gid4.y, gid4.z, gid4.w};
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 float *Fg = F + (int64_t)gv[v] * D + c0 + j16;
@@ -475,12 +500,26 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
                 }
             }
             order_fence();
+            // the next group becomes the current one, the group after it the next one
+            have = have2, have2 = have3;
+            n_blk = n_blk2, ap = ap2, pp = pp2;
+            gid4 = reinterpret_cast<const uint4 *>(grp_gid + (size_t)g2 * kGrp)[k4];
+            g2 = g3;
+            {
+                const u32 off3 = uniform(info3.x);
+                n_blk2 = max((uniform(info3.y) + 3u) >> 2, 1u);
+                ap2 = apool + (size_t)off3 * 64 + lane, pp2 = kpix + (size_t)off3 * 4 + k4;
+            }
+            g3 = claim_group(have3);
+            info3 = fetch_info(g3);
+            order_fence();
         };
         if (have) {
-            group(); // peeled: no atomics between its stream loads and its first round
+            group(); // peeled: no boundary between its stream loads and its first round
             while (have)
                 group();
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the last stream loads still target sl[]'s registers
     } else if (n_grp != 0) {
         // ---- exact sparse path for a slab with non-finite values: one record per wave at a time, lane = 2 channels ------
         const u32 nh = hdr_count[tile];
@@ -492,7 +531,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chun
             float2 acc = make_float2(0.f, 0.f);
             for (u32 e = 0; e < T; ++e) { // wave-uniform entry: a broadcast load
                 const WPair wp = wpool[woff + e];
-                const float2 f = *reinterpret_cast<const float2 *>(lds + wp.pix * kChunk + 2 * lane);
+                const float2 f = *reinterpret_cast<const float2 *>(lds + wp.pix * kRowFloats + 2 * lane);
                 acc.x = __builtin_fmaf(wp.w, f.x, acc.x);
                 acc.y = __builtin_fmaf(wp.w, f.y, acc.y);
             }
