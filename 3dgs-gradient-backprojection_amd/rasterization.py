@@ -36,8 +36,15 @@ def get_engine(device, n: int, width: int, height: int) -> Engine:
 
 
 def _front_key(view, tensors):
-    """Identity of a front-stage result: the view parameters and the Gaussian tensors (storage + in-place version)."""
-    return (bytes(view), tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors))
+    """Identity of a front-stage result: the view parameters and the Gaussian tensors' in-place versions and shapes.  The
+    tensors THEMSELVES are kept in the cache entry and compared with `is` (_same_tensors): a (data_ptr, _version) key alone
+    would match a NEW temporary that the caching allocator placed at a freed tensor's address (opac.clone() twice from a
+    fixed camera: the second call would silently reuse the first one's projection and weight store)."""
+    return (bytes(view), tuple((t._version, tuple(t.shape), tuple(t.stride())) for t in tensors))
+
+
+def _same_tensors(held, tensors) -> bool:
+    return held is not None and len(held) == len(tensors) and all(a is b for a, b in zip(held, tensors))
 
 
 def _run_front(eng: Engine, view, means, quats, scales, opacities, want_alphas, want_meta, want_store=True):
@@ -46,10 +53,12 @@ def _run_front(eng: Engine, view, means, quats, scales, opacities, want_alphas, 
 
     The reference rasterises every view TWICE with the same Gaussians -- zeros [N,512] for the features, zeros [N,3] for the
     denominators (backproject.py:115-125,133-143): the second call finds the first one's projection, sorted lists and
-    weight store in the workspace (same view bytes, same tensor storages and versions) and skips the whole front."""
-    key = _front_key(view, (means, quats, scales, opacities))
+    weight store in the workspace (same view bytes, the SAME tensor objects at the same in-place versions) and skips the
+    whole front.  Tensors that are equal but not identical (a fresh .clone() per call) are projected again."""
+    gauss = (means, quats, scales, opacities)
+    key = _front_key(view, gauss)
     c = getattr(eng, "front_cache", None)
-    if (c is not None and c["key"] == key and (c["store"] or not want_store) and (c["meta"] or not want_meta)
+    if (c is not None and c["key"] == key and _same_tensors(c["tensors"], gauss) and (c["store"] or not want_store) and (c["meta"] or not want_meta)
             and (c["alphas"] is not None or not want_alphas) and (c["halves"] or not eng._wide_requested())):
         return c["proj"], c["bins"], (c["alphas"].clone() if want_alphas else None), c["stats"]
     eng.front_cache = None
@@ -60,8 +69,9 @@ def _run_front(eng: Engine, view, means, quats, scales, opacities, want_alphas, 
         st = eng.stats()
         if not st["overflow"]:
             eng.generation += 1
-            eng.front_cache = dict(key=key, proj=proj, bins=bins, alphas=alphas, stats=st, store=want_store,
-                                   meta=want_meta, halves=want_store and eng._halves)
+            # `tensors`: strong references -- they pin the storages, so the identity test above cannot be fooled by reuse
+            eng.front_cache = dict(key=key, tensors=gauss, proj=proj, bins=bins, alphas=alphas, stats=st,
+                                   store=want_store, meta=want_meta, halves=want_store and eng._halves)
             return proj, bins, alphas, st
         eng.grow(st)
 
