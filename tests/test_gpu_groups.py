@@ -145,3 +145,54 @@ def test_pipelined_driver_uses_groups_and_matches_vector_kernels(dev):
     for r in res[1:]:
         assert r[2] == res[0][2]
         assert rel_row_err(res[0][0], r[0]) <= 1e-5 and np.abs(res[0][1] - r[1]).max() <= 1e-4 * r[1].max()
+
+
+def test_a_tile_with_more_records_than_one_sort_segment(orc, dev):
+    """k_group_sort orders a tile's records in segments of 4096: 12 000 small, faint Gaussians crowded around the image
+    centre put well over 4096 contributing records into a few tiles (no pixel terminates).  Groups path vs oracle vs the
+    128-channel vector kernel; also exercises heavy tiles in the blend's page allocation."""
+    cfg = syn.Config("HEAVY", 12_000, 1, 200, 136, 128, 0.01, False)
+    g = torch.Generator().manual_seed(21)
+    vm = syn.make_cameras(cfg)[0]
+    R, t = vm[:3, :3], vm[:3, 3]
+    # camera-space points in a 0.2 x 0.2 patch on the optical axis at the distance of the origin, back to world space
+    pc = torch.stack([(torch.rand(cfg.n_gaussians, generator=g) - 0.5) * 0.2,
+                      (torch.rand(cfg.n_gaussians, generator=g) - 0.5) * 0.2,
+                      float(t[2]) + (torch.rand(cfg.n_gaussians, generator=g) - 0.5) * 0.2], dim=1)
+    means = ((pc - t) @ R).contiguous()  # R^T (pc - t)
+    quats = torch.randn(cfg.n_gaussians, 4, generator=g)
+    scales = torch.full((cfg.n_gaussians, 3), 0.008)
+    opac = torch.full((cfg.n_gaussians,), 0.03)
+    K = syn.intrinsics(cfg)
+    D = cfg.feat_dim
+    feats = torch.randn(cfg.height, cfg.width, D, generator=g)
+    eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, group_scatter=True)
+    view = eng.view(vm, K, cfg.width, cfg.height)
+    dm, dq, ds, do = [x.to(dev) for x in (means, quats, scales, opac)]
+    while True:
+        eng.project(view, dm, dq, ds, do)
+        eng.bin_sort(view)
+        eng.blend_weights(view)
+        st = eng.stats()
+        if not st["overflow"]:
+            break
+        eng.grow(st)
+    gid, pix, w = [x.cpu().numpy() for x in eng.dump_pairs(view)]
+    tile = (pix // cfg.width // 16) * 13 + (pix % cfg.width) // 16
+    per_tile = np.bincount(np.unique(tile.astype(np.int64) * cfg.n_gaussians + gid) // cfg.n_gaussians)
+    assert per_tile.max() > 4096, per_tile.max()  # the point of the test
+    F = torch.zeros(cfg.n_gaussians, D, device=dev)
+    dd = torch.zeros(cfg.n_gaussians, device=dev)
+    eng.scatter(view, feats.to(dev), F, dd)
+    eng.set_group_scatter(False)
+    F2 = torch.zeros_like(F)
+    d2 = torch.zeros_like(dd)
+    eng.scatter(view, feats.to(dev), F2, d2)
+    assert eng.stats()["overflow"] == 0
+    Fr = np.zeros((cfg.n_gaussians, D), np.float64)
+    dr = np.zeros(cfg.n_gaussians, np.float64)
+    info = orc.backproject_view(means.numpy(), quats.numpy(), scales.numpy(), opac.numpy(), vm.numpy(), K.numpy(),
+                                cfg.width, cfg.height, feats.numpy(), Fr, dr)
+    assert info["n_pairs"] == st["n_pairs"]
+    assert rel_row_err(F.cpu().numpy(), Fr) <= TOL and rel_row_err(dd.cpu().numpy()[:, None], dr[:, None]) <= TOL
+    assert rel_row_err(F.cpu().numpy(), F2.cpu().numpy().astype(np.float64)) <= 2e-6
