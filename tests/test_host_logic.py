@@ -1,7 +1,9 @@
 """Host-side logic that needs no GPU: synthetic generators, view sharding, SH basis, reduction semantics."""
 import math
+import os
 
 import numpy as np
+import pytest
 import torch
 
 import gsbp_amd
@@ -119,3 +121,37 @@ def test_bilinear_index_matches_torch_interpolate():
         c, d = low[y1][:, x0], low[y1][:, x1]
         mine = h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d)
         assert float((mine - ref).abs().max()) <= 2e-5, ((h, w), (H, W))  # ATen vectorises the index arithmetic differently: ~5e-6
+
+
+def test_bench_starts_its_own_ranks_for_gpus_n(monkeypatch):
+    """`python bench.py --gpus N` as a plain process: bench.self_launch() must start N fresh ranks under
+    torch.distributed.run on 127.0.0.1 with the SAME arguments, before importing torch in the parent, and hand back the
+    launcher's exit code (the GPU-side end-to-end run is tests/test_gpu_two_ranks.py)."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)  # defines main / self_launch, runs nothing
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--total-views", "9"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--total-views", "9"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
