@@ -150,7 +150,10 @@ __global__ __launch_bounds__(kScatterThreads) void k_scatter(
             const u32 cnt = (u32)__popcll(m);
             const float wv = cur.wv[q]; // lanes >= cnt hold 0
             wacc += wv;
-            const int pv = pixel_list(m, lane, cnt);
+            // (tail lanes [cnt, 64) carry w = 0; they must not read a real pixel -- 0 x NaN / 0 x inf -- so they point
+            // past the slab, where an LDS read returns 0)
+            const int pl = pixel_list(m, lane, cnt); // (a full permutation: every lane takes part)
+            const int pv = (u32)lane < cnt ? pl : kTilePix + 64; // (+64: clear of the few words behind the slab as well)
             const float *qrow = lrow + q * 64 * pitch;
             // four pairs per step: independent LDS reads in flight; the tail reads unset pixels with w = 0
             for (u32 k = 0; k < cnt; k += 4) {

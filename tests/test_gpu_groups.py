@@ -98,6 +98,11 @@ def test_non_finite_features_reach_exactly_the_gaussians_that_touch_them(dev):
     got["wide"] = F.cpu().numpy()[:, :D]
     both = F.cpu().numpy()  # (the two identical halves differ only by the order of the flush atomics)
     assert np.array_equal(np.isnan(both[:, :D]), np.isnan(both[:, D:]))
+    # the generic kernel (D % 128 != 0, D > 64) on the same view: 136 channels = the map + its first 8 channels again
+    feats3 = torch.cat([feats, feats[:, :, :8]], dim=2).contiguous()
+    F = torch.zeros(cfg.n_gaussians, 136, device=dev)
+    eng.scatter(view, feats3.to(dev), F, None)
+    got["generic"] = F.cpu().numpy()[:, :D]
     for name, g in got.items():
         assert np.array_equal(np.isnan(g), np.isnan(want)), name
         assert np.array_equal(np.isposinf(g), np.isposinf(want)) and np.array_equal(np.isneginf(g), np.isneginf(want)), name
