@@ -254,6 +254,8 @@ __global__ __launch_bounds__(kPackWaves * 64) void k_pack(const Header *__restri
             for (u32 p = cnt + lane; p < n_blk * 16; p += 64)
                 s_pix[p] = last;
         }
+        // (two blocks per round -- eight gathered weights in flight per lane -- on twice as many waves was measured SLOWER:
+        // 0.83 against 0.60 ms per C2 view; the kernel moves ~2 GB, half of it the dense table it writes)
         for (u32 blk = 0; blk < n_blk; ++blk) {
             float av[4];
             u32 pk = 0;
@@ -298,7 +300,10 @@ struct Slot { // one block of a group's operand stream: A of 4 K-steps (this lan
 
 // (grp_gid, apool, kpix and F are deliberately NOT __restrict__: hipcc may then not move their loads across the
 // order_fence()s or the atomics, which is what keeps the counted waits of the operand stream exact)
-__global__ __launch_bounds__(kThreads) void k_scatter_mfma(ViewDev V, int n_chunks, const uint2 *__restrict__ tile_grp,
+// (waves_per_eu(5, 5): 96 VGPRs instead of 118 -- the spilled values are per-thread constants reloaded at item and group
+// boundaries; alone the kernel loses 0.1 ms, in the two-stream pipeline the front stage gets its second wave per SIMD back:
+// 5.5 -> 4.9 ms per C2 view)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_scatter_mfma(ViewDev V, int n_chunks, const uint2 *__restrict__ tile_grp,
                                                           const GrpInfo *__restrict__ grp_info, const u32 *grp_gid,
                                                           const float4 *apool, const u32 *kpix,
                                                           const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
