@@ -110,15 +110,19 @@ class Engine:
             self.caps.flags &= ~_lib.FLAG_GROUP_SCATTER
 
     def _alloc(self):
-        keep = self.caps.flags & (_lib.FLAG_FRONT_PRIORITY | _lib.FLAG_NARROW_SCATTER) if hasattr(self, "caps") else \
-            _lib.FLAG_NARROW_SCATTER
-        # the workspace is SIZED with the group tables when the engine is group-capable; they sit behind everything else, so
-        # calls without the flag use the same workspace
-        self.caps = Caps(self.n, self.isect_cap, self.pair_cap, self.max_w, self.max_h, self.scatter_workgroups,
-                         (_lib.FLAG_TIGHT_BINNING if self.tight_binning else 0) | keep |
-                         (_lib.FLAG_GROUP_SCATTER if self.group_capable else 0))
+        # run-time flags survive a re-allocation (grow); a new engine starts narrow, with the block-sparse scatter on if it is
+        # group-capable
+        run = (self.caps.flags & (_lib.FLAG_FRONT_PRIORITY | _lib.FLAG_NARROW_SCATTER | _lib.FLAG_GROUP_SCATTER)
+               if hasattr(self, "caps") else
+               _lib.FLAG_NARROW_SCATTER | (_lib.FLAG_GROUP_SCATTER if self.group_capable else 0))
+        base = _lib.FLAG_TIGHT_BINNING if self.tight_binning else 0
+        # the workspace is SIZED with the group tables when the engine is group-capable (they sit behind everything else, so
+        # calls without the flag use the same workspace), whatever the run-time state of the flag
+        size_caps = Caps(self.n, self.isect_cap, self.pair_cap, self.max_w, self.max_h, self.scatter_workgroups,
+                         base | (_lib.FLAG_GROUP_SCATTER if self.group_capable else 0))
         nbytes = C.c_size_t(0)
-        self._call("gwbp_workspace_size", C.byref(self.caps), C.byref(nbytes))
+        self._call("gwbp_workspace_size", C.byref(size_caps), C.byref(nbytes))
+        self.caps = Caps(self.n, self.isect_cap, self.pair_cap, self.max_w, self.max_h, self.scatter_workgroups, base | run)
         self.ws_bytes = int(nbytes.value)
         self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.device)
         off = (-self.ws.data_ptr()) % 256
