@@ -444,6 +444,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))
             sl[u].a = ap[(size_t)bb * 64], sl[u].p = pp[(size_t)bb * 4];
         }
         order_fence();
+        u32 exp_counter = (u32)(threadIdx.x >> 6); // (experiment builds only)
+        (void)exp_counter;
         auto group = [&]() __attribute__((always_inline)) {
             const u32 cur_blk = n_blk;
             f32x4_t acc[8];
@@ -456,7 +458,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))
                 for (int u = 0; u < kPF; ++u) {
                     const float4 a4 = sl[u].a;
                     const u32 p4 = sl[u].p;
+#ifdef GWBP_NO_COMPUTE // experiment build only
+                    if (false) {
+#else
                     if (blk0 + u < cur_blk && !(dbg & 2)) { // wave-uniform; no memory operation inside
+#endif
                         const float av[4] = {a4.x, a4.y, a4.z, a4.w};
                         // all four K-steps of a block run: k_pack zero-fills the K-steps past the group's last one.
                         // (Issuing the eight B reads of K-step t + 1 ahead of the MFMAs of K-step t -- two register sets,
@@ -491,10 +497,22 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))
             // contiguous bytes per instruction.
             order_fence();
             const u32 gv[4] = {gid4.x, gid4.y, gid4.z, gid4.w};
+#ifdef GWBP_FEWER_FLUSHES // experiment builds only (results invalid): 3 of 8 groups (1, 2) or all of them (3) "flush" with
+                          // plain stores -- same VMEM count; 2 and 3: into one L2-resident row per workgroup
+            const bool plain = GWBP_FEWER_FLUSHES == 3 || (exp_counter++ & 7u) >= 5u;
+#else
+            constexpr bool plain = false;
+#endif
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 float *Fg = F + (int64_t)gv[v] * D + c0 + j16;
-                if (!(dbg & 1)) {
+#ifdef GWBP_FEWER_FLUSHES
+#if GWBP_FEWER_FLUSHES >= 2 // ... and those stores go to one L2-resident line set per workgroup: no memory-side cost at all
+                if (plain)
+                    Fg = F + (int64_t)(blockIdx.x & 255u) * D + c0 + j16;
+#endif
+#endif
+                if (!(dbg & 1) && !plain) {
 #pragma unroll
                     for (int n = 0; n < 8; ++n)
                         atomicAdd(Fg + 16 * n, acc[n][v] * scale_f);
