@@ -206,6 +206,16 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
             const float *src = feats + offs[u] + c0 + lane;
             vals[u] = make_float4(src[0], src[64], src[128], src[192]);
         }
+#ifdef GWBP_STAGING_ATOMICS // experiment build only: GWBP_STAGING_ATOMICS extra atomic wave-instructions per wave and pass,
+                            // issued BEHIND the staging loads, into this workgroup's carry slice -- are atomics free in the
+                            // staging shadow (per-CU issue limit) or not (chip-wide limit)?
+        {
+            float *dummy = carry + (size_t)(threadIdx.x >> 6) * kWide + lane;
+#pragma unroll
+            for (int e = 0; e < GWBP_STAGING_ATOMICS; ++e)
+                atomicAdd(dummy + 64 * (e & 3) + 4096 * (e >> 2), 1.0f);
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < kUnits; ++u) {
             const int idx = u * kThreads + threadIdx.x;
