@@ -43,14 +43,13 @@ class Stats(C.Structure):
                 ("reserved", C.c_uint32)]
 
     def as_dict(self):
-        # ("reserved" = what the last blend left in the workspace: 0 store, 1 + half-tile lists, 2 nothing, 3 + record groups)
+        # ("reserved" = what the last blend left in the workspace: 0 store, 1 + half-tile lists, 2 nothing)
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"} | {"blend_kind": int(self.reserved)}
 
 
 FLAG_TIGHT_BINNING = 1  # GWBP_FLAG_TIGHT_BINNING (include/gwbp.h)
 FLAG_FRONT_PRIORITY = 2  # GWBP_FLAG_FRONT_PRIORITY
 FLAG_NARROW_SCATTER = 4  # GWBP_FLAG_NARROW_SCATTER
-FLAG_GROUP_SCATTER = 8  # GWBP_FLAG_GROUP_SCATTER: block-sparse scatter on the matrix cores (D % 128 == 0)
 
 
 class GwbpError(RuntimeError):

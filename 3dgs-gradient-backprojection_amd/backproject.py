@@ -131,9 +131,8 @@ class ViewPipeline:
 
     def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None,
                  allow_wide: bool = True, scatter_workgroups: Optional[int] = None, side_priority: int = -1,
-                 front_priority: Optional[bool] = None, fuse_small: bool = True, allow_groups: bool = False):
+                 front_priority: Optional[bool] = None, fuse_small: bool = True):
         self.dev = torch.device(device)
-        self.allow_groups = bool(allow_groups)
         self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev, tight_binning=True)
                                                   for _ in range(2)]
         # Scatter grid under overlap: one persistent workgroup per CU is the measured optimum once the front stage is
@@ -192,20 +191,14 @@ class ViewPipeline:
         are pending: every Engine remembers whether the view in its workspace was blended with the half-tile lists, and
         scatters a view blended without them through the 128-channel kernel (front() likewise recorded whether it has
         already added that view's denominators)."""
-        # the block-sparse (matrix-core) scatter: every engine of the pipeline was built with group_scatter=True and the
-        # channel count suits it; it leaves the vector ALUs to the front stage, so no raised priority is needed
-        groups = (self.allow_groups and self.scatter_dim is not None and self.scatter_dim % 128 == 0
-                  and all(e.group_capable for e in self.eng))
-        wide = not groups and self.allow_wide and self.scatter_dim is not None and self.scatter_dim % 256 == 0
+        wide = self.allow_wide and self.scatter_dim is not None and self.scatter_dim % 256 == 0
         if wide and n_pairs is not None and n_headers:
             wide = n_pairs / n_headers >= self.WIDE_MIN_PAIRS_PER_RECORD
-        self.wide, self.groups = wide, groups
+        self.wide = wide
         for e in self.eng:
-            if e.group_capable:
-                e.set_group_scatter(groups)
             e.set_narrow_scatter(not wide)
-            e.set_front_priority((wide or groups) if self.front_priority is None else bool(self.front_priority))
-        return "groups" if groups else "wide" if wide else "narrow"
+            e.set_front_priority(wide if self.front_priority is None else bool(self.front_priority))
+        return "wide" if wide else "narrow"
 
     def front(self, view, means, quats, scales, opacities, d=None, scale_d=1.0):
         """d (optional): the denominator accumulator.  With the 256-channel scatter kernel chosen, the view's share of d
@@ -231,7 +224,7 @@ class ViewPipeline:
             e = self.eng[b]
             e.project(view, means, quats, scales, opacities)
             e.bin_sort(view)
-            d_done = d is not None and (self.wide or self.groups) and not self.fuse_small
+            d_done = d is not None and self.wide and not self.fuse_small
             if not self.fuse_small:
                 e.blend_weights(view, d=d if d_done else None, scale_d=scale_d)
             self.ev_front[b].record(side)
@@ -395,7 +388,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                          views: Optional[Sequence[int]] = None, view_fn=None, pipeline: bool = True,
                          return_partials: bool = False, verbose: bool = False, upsample: Optional[str] = None,
                          gather: bool = True, allow_wide: bool = True, fuse_encoder: bool = False,
-                         fuse_small: bool = True, feature_fn_stream_safe: bool = False, allow_groups: bool = False):
+                         fuse_small: bool = True, feature_fn_stream_safe: bool = False):
     """Build the [N, dim_out] per-Gaussian feature field.
 
     means/quats/scales/opacities: post-activation Gaussians (backproject.py:55-57), device tensors.
@@ -415,10 +408,6 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     kernel one view ahead on a third stream (gwbp_encode_map).
     fuse_small: maps of at most 16 channels (after the encoder) are blended AND scattered by one kernel
     (gwbp_blend_scatter: no weight store, no scatter kernel; C5 1.96 -> 1.42 ms/view); False keeps the two-kernel form.
-    allow_groups: D % 128 == 0 full-resolution maps go through the block-sparse scatter on the matrix cores
-    (GWBP_FLAG_GROUP_SCATTER, csrc/scatter_mfma.hip).  Opt-in: measured slower than the vector kernels at one flush per
-    (Gaussian, tile) (C2: 3.7 ms alone against 3.3); False (default) keeps the vector kernels
-    (allow_wide picks between them).
     feature_fn_stream_safe: STREAM CONTRACT of feature_fn.  False (default): feature_fn runs on the caller's current stream
     and every map is handed to its consumer stream with an event -- any feature function is safe, including one that
     returns a prefetched tensor, reuses a static output buffer or replays a graph (the buffer must still not be overwritten
@@ -450,20 +439,14 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     t0 = time.time()
     stats: Dict[str, int] = {}
     if view_fn is None:
-        # allow_groups: the block-sparse (matrix-core) scatter for D % 128 == 0 full-resolution maps; an engine handed in by
-        # the caller decides for itself (Engine(group_scatter=...))
-        want_groups = allow_groups and d_out % 128 == 0 and upsample is None
-        eng = engine or Engine(n, width, height, device=dev, tight_binning=True,  # same F and d, shorter tile lists
-                               group_scatter=want_groups)
+        eng = engine or Engine(n, width, height, device=dev, tight_binning=True)  # same F and d, shorter tile lists
         for attempt in range(6):  # a capacity overflow invalidates the accumulators: grow the workspace, start over
             if pipeline and len(my_views) > 1:
                 depth = pipeline_depth(n, width, height) if pipeline is True else max(2, int(pipeline))
                 pipe = ViewPipeline(n, width, height, dev, scatter_dim=d_out,
                                     allow_wide=allow_wide, fuse_small=fuse_small and not (fuse_encoder and encoder is not None),
-                                    allow_groups=want_groups,
                                     engines=[eng] + [Engine(n, width, height, device=dev, tight_binning=eng.tight_binning,
-                                                            isect_cap=eng.isect_cap, pair_cap=eng.pair_cap,
-                                                            group_scatter=eng.group_capable)
+                                                            isect_cap=eng.isect_cap, pair_cap=eng.pair_cap)
                                                      for _ in range(depth - 1)])
                 views = [eng.view(vm_host[v], K_host, width, height) for v in my_views]
                 for j in range(min(pipe.lookahead, len(my_views))):

@@ -28,12 +28,11 @@ constexpr int kBatch = 64;
 // What a contributing record turns into.
 //   kStore:  entries {w, pixel} + Header in the weight store (read by k_scatter_full / k_scatter / k_render_*)
 //   kHalves: the same plus the half-tile record lists and weight sums the 256-channel scatter kernel reads
-//   kGroups: kStore plus the weight sums (no half-tile lists): what the block-sparse scatter's grouping pass reads
 //   kFused:  NO store: the record's sums  F[gid, :D] += sum_p w f[p, :],  d[gid] += sum_p w  are formed right here from
 //            the tile's pixels held in registers (D <= 16: 4 pixels x 16 channels = 64 VGPRs per lane) and added to F / d
 //            with one atomic instruction -- the small-D variants (backproject_compressed.py:127-165: D = 16) then need
 //            neither the 0.8 GB store nor a scatter kernel.
-enum BlendMode { kStore = 0, kHalves = 1, kFused = 2, kGroups = 3 };
+enum BlendMode { kStore = 0, kHalves = 1, kFused = 2 };
 constexpr int kFusedCh = 16;
 
 struct FusedArgs { // kFused only
@@ -156,11 +155,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                                               u32 *__restrict__ hdr_count, WPair *__restrict__ wpool, u32 pair_cap,
                                               u32 *__restrict__ shards, const u32 *__restrict__ tile_order, float *__restrict__ alphas,
                                               HalfHdr *__restrict__ half_a, HalfHdr *__restrict__ half_b,
-                                              u32 *__restrict__ half_cnt_a, u32 *__restrict__ half_cnt_b, int dbg, int prio,
+                                              u32 *__restrict__ half_cnt_a, u32 *__restrict__ half_cnt_b, int dbg_arg, int prio,
                                               float *__restrict__ d_out, float scale_d, FusedArgs fu)
 {
+#ifdef GWBP_PROFILE
+    const int dbg = dbg_arg; // ablation bits (make PROFILE=1 only; results invalid)
+#else
+    constexpr int dbg = 0;   // the product kernel does not even contain the ablation branches
+    (void)dbg_arg;
+#endif
     constexpr bool HALVES = MODE == kHalves;
-    constexpr bool WSUM = MODE == kHalves || MODE == kGroups; // the record's weight sum in its header (+ d[gid] right here)
+    constexpr bool WSUM = MODE == kHalves; // the record's weight sum in its header (+ d[gid] right here)
     front_priority(prio);
     __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
     __shared__ float4 s_b[kBatch]; // ca, cb, cc, strip mask
@@ -468,9 +473,15 @@ __global__ __launch_bounds__(64) void k_blend_scatter_quarter(ViewDev V, const u
                                                               const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
                                                               Counters *__restrict__ ctr, u32 *__restrict__ hdr_count,
                                                               const u32 *__restrict__ tile_order, float *__restrict__ alphas,
-                                                              int dbg, int prio, float *__restrict__ d_out, float scale_d,
+                                                              int dbg_arg, int prio, float *__restrict__ d_out, float scale_d,
                                                               FusedArgs fu)
 {
+#ifdef GWBP_PROFILE
+    const int dbg = dbg_arg; // ablation bits (make PROFILE=1 only; results invalid)
+#else
+    constexpr int dbg = 0;   // the product kernel does not even contain the ablation branches
+    (void)dbg_arg;
+#endif
     front_priority(prio);
     __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
     __shared__ float4 s_b[kBatch]; // ca, cb, cc, "may reach this quarter"
@@ -661,7 +672,7 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
         fu.feats = M->p, fu.fs_y = M->fs_y, fu.fs_x = M->fs_x, fu.D = D, fu.scale_f = scale_f, fu.F = F;
         fu.vec4 = (D % 4 == 0 && M->fs_y % 4 == 0 && M->fs_x % 4 == 0 && (reinterpret_cast<uintptr_t>(M->p) & 15) == 0) ? 1 : 0;
     }
-    if (!fused && d && (L.flags & GWBP_FLAG_NARROW_SCATTER) && !(L.flags & GWBP_FLAG_GROUP_SCATTER))
+    if (!fused && d && (L.flags & GWBP_FLAG_NARROW_SCATTER))
         return set_error(GWBP_EINVAL, "gwbp_blend_weights_d needs a blend without GWBP_FLAG_NARROW_SCATTER (no weight sums)");
     const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
     const int n_tiles = V.tile_w * V.tile_h;
@@ -684,8 +695,6 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
 #undef GWBP_QUARTER
     } else if (fused)
         GWBP_BLEND(kFused);
-    else if (L.flags & GWBP_FLAG_GROUP_SCATTER)
-        GWBP_BLEND(kGroups);
     else if (L.flags & GWBP_FLAG_NARROW_SCATTER)
         GWBP_BLEND(kStore);
     else // (the half-tile lists as a streaming kernel of their own behind a list-less blend -- 0.65 + 0.05 ms alone instead of
@@ -694,12 +703,8 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
 #undef GWBP_BLEND
     if (!fused)
         hipLaunchKernelGGL(k_pool_stats, dim3(1), dim3(1), 0, s, W.shards, W.counters,
-                           (L.flags & GWBP_FLAG_GROUP_SCATTER) ? kBlendGroups
-                           : (L.flags & GWBP_FLAG_NARROW_SCATTER) ? 0u : kBlendHalves);
-    int rc = check_hip(hipGetLastError(), "blend launch");
-    if (rc == GWBP_OK && !fused && (L.flags & GWBP_FLAG_GROUP_SCATTER))
-        rc = launch_pack_groups(L, W, V, s); // record groups + dense operand tables of the block-sparse scatter
-    return rc;
+                           (L.flags & GWBP_FLAG_NARROW_SCATTER) ? 0u : kBlendHalves);
+    return check_hip(hipGetLastError(), "blend launch");
 }
 
 int launch_dump_pairs(const Layout &L, const Ws &W, const ViewDev &V, int64_t cap, int32_t *gid, int32_t *pix,

@@ -95,6 +95,8 @@ int make_layout(const gwbp_caps *c, Layout *L)
         return set_error(GWBP_EINVAL, "caps out of range (N=%lld isect_cap=%lld pair_cap=%lld %dx%d)",
                          (long long)c->n_gaussians, (long long)c->isect_cap, (long long)c->pair_cap, c->max_width,
                          c->max_height);
+    if (c->flags & ~(GWBP_FLAG_TIGHT_BINNING | GWBP_FLAG_FRONT_PRIORITY | GWBP_FLAG_NARROW_SCATTER))
+        return set_error(GWBP_EINVAL, "unknown caps.flags bits 0x%x", (unsigned)c->flags);
     memset(L, 0, sizeof(*L));
     L->n = c->n_gaussians;
     L->isect_cap = c->isect_cap;
@@ -113,7 +115,6 @@ int make_layout(const gwbp_caps *c, Layout *L)
     };
     L->counters = take(sizeof(Counters));
     L->shards = take((size_t)(kShards + kQueues) * 64);
-    L->pack_ctr = take(64); // directly behind the shard / queue words: zeroed by the same memset (launch_project)
     L->g2d = take((size_t)L->n * sizeof(G2D));
     L->rect = take((size_t)L->n * sizeof(uint2));
     L->touched = take((size_t)L->n * sizeof(u32));
@@ -138,20 +139,6 @@ int make_layout(const gwbp_caps *c, Layout *L)
     }
     L->carry = take((size_t)kCarryWgs * kCarryRows * 256 * sizeof(float));
     L->wpool = take((size_t)L->pair_cap * sizeof(WPair));
-    if (c->flags & GWBP_FLAG_GROUP_SCATTER) {
-        // groups: every tile rounds its record count up to a multiple of 16 (+1 per 4096-record segment of a long list)
-        L->grp_cap = L->isect_cap / kGrp + 2 * (int64_t)L->max_tiles;
-        // blocks of 4 K-steps x 4 pixels: pairs / 16 would be a fully dense table; the union of 16 footprints is measured
-        // at ~2.8x one footprint (C2), and short groups round up -- pair_cap / 3 + one block per group is ample; overflow
-        // raises gwbp_stats.overflow bit 3 and the host grows pair_cap
-        L->blk_cap = L->pair_cap / 3 / 16 + L->grp_cap;
-        L->tile_grp = take((size_t)L->max_tiles * sizeof(uint2));
-        L->grp_info = take((size_t)L->grp_cap * sizeof(GrpInfo));
-        L->grp_gid = take((size_t)L->grp_cap * kGrp * sizeof(u32));
-        L->grp_rec = take((size_t)L->grp_cap * kGrp * sizeof(u32));
-        L->apool = take((size_t)L->blk_cap * 64 * sizeof(float4));
-        L->kpix = take((size_t)L->blk_cap * 4 * sizeof(u32));
-    }
     L->total = o;
     return GWBP_OK;
 }
@@ -194,14 +181,6 @@ int bind_workspace(const gwbp_caps *caps, void *ws, size_t bytes, Layout *L, Ws 
     }
     W->carry = reinterpret_cast<float *>(b + L->carry);
     W->wpool = reinterpret_cast<WPair *>(b + L->wpool);
-    W->pack_ctr = reinterpret_cast<u32 *>(b + L->pack_ctr);
-    const bool grp = (caps->flags & GWBP_FLAG_GROUP_SCATTER) != 0;
-    W->tile_grp = grp ? reinterpret_cast<uint2 *>(b + L->tile_grp) : nullptr;
-    W->grp_info = grp ? reinterpret_cast<GrpInfo *>(b + L->grp_info) : nullptr;
-    W->grp_gid = grp ? reinterpret_cast<u32 *>(b + L->grp_gid) : nullptr;
-    W->grp_rec = grp ? reinterpret_cast<u32 *>(b + L->grp_rec) : nullptr;
-    W->apool = grp ? reinterpret_cast<float4 *>(b + L->apool) : nullptr;
-    W->kpix = grp ? reinterpret_cast<u32 *>(b + L->kpix) : nullptr;
     return GWBP_OK;
 }
 

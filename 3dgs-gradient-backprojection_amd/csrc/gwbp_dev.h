@@ -65,20 +65,6 @@ struct __attribute__((aligned(16))) HalfHdr {
     u32 n_span; // entries in this half (1..128) | spans-both-halves-and-has-a-carry-row << 8
     u32 row;    // carry row: the record's index in list A of its tile (valid when the span bit is set)
 };
-// ---- block-sparse (matrix-core) scatter: groups of 16 records of one tile --------------------------------------------
-// k_group_sort orders a tile's records by the coarse bounding box of their pixel masks and cuts the order into groups of
-// kGrp; k_pack turns each group into a DENSE operand table: K-step = 4 pixels of the union of the group's footprints,
-// A[record i][pixel k] = the record's weight at that pixel or 0.  Four K-steps form a block: apool[blk][lane] is the float4
-// {A(4 blk + t)[lane], t = 0..3} (lane = 16 k + i, the MFMA A layout), kpix[blk][k] the four pixel bytes of slot k.
-constexpr int kGrp = 16;
-struct GrpInfo {
-    u32 blk_off; // first block of the group in apool / kpix
-    u32 n_ks;    // K-steps (4 pixels each); 0 = nothing to do (empty or dropped on overflow)
-};
-// pack_ctr words (zeroed with the counters at projection time)
-constexpr int kPackGroups = 0, kPackBlocks = 1;
-constexpr u32 kOverflowGroups = 8u; // gwbp_stats::overflow bit 3: group / block capacity of the block-sparse scatter exceeded
-
 constexpr int kCarryRows = 1024; // carry rows per scatter workgroup; records of list A beyond it are flushed per half
 constexpr int kCarryWgs = 256;   // scatter workgroups that own a carry slice (persistent grid: one per CU)
 
@@ -94,15 +80,14 @@ struct Counters {
 };
 constexpr u32 kBlendHalves = 1u;
 constexpr u32 kBlendFused = 2u; // gwbp_blend_scatter: the view was blended AND scattered, its weight store is empty
-constexpr u32 kBlendGroups = 3u; // weight store + weight sums + the record groups / dense operand tables of k_scatter_mfma
 constexpr u32 kOverflowMismatch = 4u; // gwbp_stats::overflow bit 2, see include/gwbp.h
 static_assert(sizeof(Counters) == sizeof(gwbp_stats), "Counters must mirror gwbp_stats");
 
 struct Layout {
     size_t total;
     size_t counters, shards, g2d, rect, touched, blocksums, dkeys[2], dvals[2], keys[2], vals[2], hist, digit_total, tile_offsets, tile_order, hdr_count,
-        headers, half[2], half_count[2], carry, wpool, pack_ctr, tile_grp, grp_info, grp_gid, grp_rec, apool, kpix;
-    int64_t n, isect_cap, pair_cap, grp_cap, blk_cap;
+        headers, half[2], half_count[2], carry, wpool;
+    int64_t n, isect_cap, pair_cap;
     int max_tiles, n_scan_blocks, n_sort_blocks, scatter_wgs, flags;
 };
 
@@ -126,14 +111,6 @@ struct Ws {
     u32 *half_count[2];  // per tile
     float *carry;        // kCarryWgs x kCarryRows x 256 floats
     WPair *wpool;
-    // block-sparse scatter (GWBP_FLAG_GROUP_SCATTER)
-    u32 *pack_ctr;       // kPackGroups, kPackBlocks
-    uint2 *tile_grp;     // per tile: first group, number of groups
-    GrpInfo *grp_info;   // per group
-    u32 *grp_gid;        // per group: kGrp Gaussian ids (empty slots repeat the group's first record's id)
-    u32 *grp_rec;        // per group: kGrp header indices (0xFFFFFFFF = empty slot)
-    float4 *apool;       // blk_cap x 64 float4
-    u32 *kpix;           // blk_cap x 4
 };
 
 int make_layout(const gwbp_caps *caps, Layout *L);
@@ -218,11 +195,6 @@ int launch_scatter_full(const Layout &L, const Ws &W, const ViewDev &V, const Fe
                         float scale_d, float *F, float *d, hipStream_t s);
 int launch_accum_d(const Layout &L, const Ws &W, const ViewDev &V, float scale_d, float *d, hipStream_t s);
 int launch_scatter_wide(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
-                        float *F, hipStream_t s);
-// block-sparse scatter on the matrix cores (scatter_mfma.hip): the grouping + packing pass behind the blend, and the kernel
-int launch_pack_groups(const Layout &L, const Ws &W, const ViewDev &V, hipStream_t s);
-bool scatter_mfma_takes(const FeatMap &M, int D);
-int launch_scatter_mfma(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap &M, int D, float scale_f,
                         float *F, hipStream_t s);
 int launch_render(const Layout &L, const Ws &W, const ViewDev &V, const float *colors, int D, float *out,
                   hipStream_t s);

@@ -326,8 +326,8 @@ int launch_project(const Layout &L, const Ws &W, const ViewDev &V, const float *
                    float *conics, hipStream_t s)
 {
     const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
-    // counters, the pool shard heads / scatter queues and the group-packing counters are adjacent sub-buffers: one memset node
-    int rc = check_hip(hipMemsetAsync(W.counters, 0, (size_t)((char *)W.pack_ctr - (char *)W.counters) + 64, s),
+    // counters and the pool shard heads / scatter queues are adjacent sub-buffers (g2d follows): one memset node
+    int rc = check_hip(hipMemsetAsync(W.counters, 0, L.g2d - L.counters, s),
                        "memset counters");
     if (rc)
         return rc;

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_accum_d(const u32 *__restrict__ tile_of
                                                  const Header *__restrict__ headers, float scale_d,
                                                  float *__restrict__ dsum_out, Counters *__restrict__ ctr)
 {
-    if (ctr->blend_kind != kBlendHalves && ctr->blend_kind != kBlendGroups) { // no weight sums in this view's headers: refuse, flag (see k_scatter_wide)
+    if (ctr->blend_kind != kBlendHalves) { // no weight sums in this view's headers: refuse, flag (see k_scatter_wide)
         if (blockIdx.x == 0 && threadIdx.x == 0)
             atomicOr(&ctr->overflow, kOverflowMismatch);
         return;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_accum_d(const u32 *__restrict__ tile_of
 
 int launch_accum_d(const Layout &L, const Ws &W, const ViewDev &V, float scale_d, float *d, hipStream_t s)
 {
-    if ((L.flags & GWBP_FLAG_NARROW_SCATTER) && !(L.flags & GWBP_FLAG_GROUP_SCATTER))
+    if (L.flags & GWBP_FLAG_NARROW_SCATTER)
         return set_error(GWBP_EINVAL, "gwbp_accumulate_d needs a blend without GWBP_FLAG_NARROW_SCATTER (no weight sums)");
     const int n_tiles = V.tile_w * V.tile_h;
     if (d && n_tiles > 0)
@@ -286,17 +286,8 @@ int launch_scatter(const Layout &L, const Ws &W, const ViewDev &V, const FeatMap
         if (rc)
             return rc;
     }
-    // block-sparse scatter on the matrix cores (scatter_mfma.hip): the view was blended with GWBP_FLAG_GROUP_SCATTER
-    if ((L.flags & GWBP_FLAG_GROUP_SCATTER) && scatter_mfma_takes(M, D)) {
-        if (d) {
-            const int rc = launch_accum_d(L, W, V, scale_d, d, s);
-            if (rc)
-                return rc;
-        }
-        return launch_scatter_mfma(L, W, V, M, D, scale_f, F, s);
-    }
     // fast paths: D % 256 == 0 channel-contiguous (scatter_wide.hip); D % 128 == 0 or D <= 64, any strides (scatter_full.hip)
-    if (!(L.flags & GWBP_FLAG_GROUP_SCATTER) && D % 256 == 0 && M.fs_c == 1 && !(L.flags & GWBP_FLAG_NARROW_SCATTER)) {
+    if (D % 256 == 0 && M.fs_c == 1 && !(L.flags & GWBP_FLAG_NARROW_SCATTER)) {
         if (d) {
             const int rc = launch_accum_d(L, W, V, scale_d, d, s);
             if (rc)

@@ -119,8 +119,15 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
     ViewDev V, int n_chunks, const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
     const Header *__restrict__ headers, const WPair *__restrict__ wpool, FeatMap M, int pitch_rt, int D,
     float scale_f, float scale_d, float *__restrict__ F, float *__restrict__ dsum_out, u32 *__restrict__ queues,
-    int dbg)
+    int dbg_arg)
 {
+#ifdef GWBP_PROFILE
+    const int dbg = dbg_arg; // ablation bits (make PROFILE=1 only; results invalid)
+#else
+    constexpr int dbg = 0;   // the product kernel does not even contain the ablation branches
+    (void)dbg_arg;
+#endif
+
     const float *__restrict__ feats = M.p;
     const int64_t fs_c = M.fs_c;
     const int pitch = SMALL ? pitch_rt : kChunk;

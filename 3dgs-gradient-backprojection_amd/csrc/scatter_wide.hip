@@ -36,7 +36,7 @@
 
 namespace gwbp {
 
-#ifdef GWBP_PROFILE
+#ifdef GWBP_STAMPS
 // In-kernel stamps (PROFILE build only, tools/stamp_scatter.py): shader cycles summed over the waves of all workgroups,
 // [0] slab staging incl. its barrier, [1] visit loop, [2] drain (s_waitcnt vmcnt(0)), [3] end-of-phase barrier wait,
 // [4] phases, [5] visits.
@@ -108,6 +108,19 @@ __device__ __forceinline__ void wait_pre(Pre &x)
                  : "memory");
 }
 
+// Structure-preserving ablations (make PROFILE=1 ABL=<bits>; results INVALID by design, never in the product library):
+// compile-time, so every build keeps the visit's VMEM count and hence its counted waits.
+//   1  every flush = plain stores into ONE L2-resident row of the workgroup's carry slice (no memory-side atomic cost)
+//   2  no LDS reads / FMAs
+//   4  no slab staging
+//   8  with 1: only 3 of 8 visits flush that way (what merging 2 x 2 tile blocks would save)
+//  16  parks and resumes all use carry row 0 (no carry traffic beyond L2)
+#if defined(GWBP_PROFILE) && defined(GWBP_ABL)
+constexpr int kAbl = GWBP_ABL;
+#else
+constexpr int kAbl = 0;
+#endif
+
 constexpr int kLoads = 6;  // VMEM loads per visit (prefetch)
 constexpr int kFlush = 4;  // VMEM flush operations per visit
 
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     ViewDev V, int n_chunks, const u32 *__restrict__ tile_offsets, const u32 *__restrict__ cnt_a,
     const u32 *__restrict__ cnt_b, const HalfHdr *__restrict__ half_a, const HalfHdr *__restrict__ half_b,
     const WPair *__restrict__ wpool, FeatMap M, int D, float scale_f, float *__restrict__ F,
-    u32 *__restrict__ queues, float *__restrict__ carry_all, Counters *__restrict__ ctr, int dbg)
+    u32 *__restrict__ queues, float *__restrict__ carry_all, Counters *__restrict__ ctr)
 {
     // The half-tile lists exist only if THIS view was blended without GWBP_FLAG_NARROW_SCATTER; otherwise they are
     // uninitialised or a previous view's.  Refuse (F untouched, overflow bit 2 raised) instead of scattering garbage.
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     if (threadIdx.x == 0)
         s_item[0] = atomicAdd(queue, 1u);
     __syncthreads();
-#ifdef GWBP_PROFILE
+#ifdef GWBP_STAMPS
     unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
 #endif
     for (u32 k = 0;; ++k) {
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     u32 nxt = 0;
     if (phase == 0 && threadIdx.x == 0)
         nxt = atomicAdd(queue, 1u); // claim the next item under the slab loads
-    if (!(dbg & 4) && nh != 0 && M.bilinear()) {
+    if (!(kAbl & 4) && nh != 0 && M.bilinear()) {
         // Bilinear low-resolution map (backproject.py:110-112 folded in): every slab value is the blend of four texels
         // (L2 / Infinity-Cache resident: the 480 x 480 x 512 map of the lseg script is 472 MB), in ATen's association.
         // One (pixel, lane) unit per round: 16 dword loads in flight per thread.
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
             if (kAll % kThreads == 0 || u * kThreads + (int)threadIdx.x < kAll)
                 *reinterpret_cast<float4 *>(lds + (idx >> 6) * kWide + 4 * lane) = make_float4(r[0], r[1], r[2], r[3]);
         }
-    } else if (!(dbg & 4) && nh != 0) {
+    } else if (!(kAbl & 4) && nh != 0) {
         // stage 128 px x 256 ch: unit = (pixel, lane) -> 4 coalesced dword loads + one ds_write_b128; 8 units per thread
         constexpr int kAll = kHalfPix * 64;                          // 8192 (pixel, lane) units
         constexpr int kUnits = (kAll + kThreads - 1) / kThreads;     // 8 at 1024 threads
@@ -206,16 +219,6 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
             const float *src = feats + offs[u] + c0 + lane;
             vals[u] = make_float4(src[0], src[64], src[128], src[192]);
         }
-#ifdef GWBP_STAGING_ATOMICS // experiment build only: GWBP_STAGING_ATOMICS extra atomic wave-instructions per wave and pass,
-                            // issued BEHIND the staging loads, into this workgroup's carry slice -- are atomics free in the
-                            // staging shadow (per-CU issue limit) or not (chip-wide limit)?
-        {
-            float *dummy = carry + (size_t)(threadIdx.x >> 6) * kWide + lane;
-#pragma unroll
-            for (int e = 0; e < GWBP_STAGING_ATOMICS; ++e)
-                atomicAdd(dummy + 64 * (e & 3) + 4096 * (e >> 2), 1.0f);
-        }
-#endif
 #pragma unroll
         for (int u = 0; u < kUnits; ++u) {
             const int idx = u * kThreads + threadIdx.x;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         s_item[(k + 1u) & 1u] = nxt;
     __syncthreads();
     GWBP_STAMP(ts1);
-#ifdef GWBP_PROFILE
+#ifdef GWBP_STAMPS
     u32 n_vis_prof = 0;
 #endif
 
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
             issue_e(x.e[j], wpool + (R.off + min((u32)(64 * j + lane), last)));
         if constexpr (decltype(bottom)::value) {
             // carry dwords of this lane (non-spanning records: row 0, value ignored -- the count must stay exact)
-            const float *cr = carry + (size_t)(R.span ? R.row : 0u) * kWide + lane;
+            const float *cr = carry + (size_t)((R.span && !(kAbl & 16)) ? R.row : 0u) * kWide + lane;
             issue_c<0>(x.c[0], cr);
             issue_c<256>(x.c[1], cr);
             issue_c<512>(x.c[2], cr);
@@ -312,12 +315,12 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
 #undef GWBP_FMA
     };
     auto process = [&](const Visit &R, const Pre &x) __attribute__((always_inline)) { // exactly kFlush VMEM operations
-#ifdef GWBP_PROFILE
+#ifdef GWBP_STAMPS
         ++n_vis_prof;
 #endif
         const bool resume = phase && R.span;
         acc = resume ? make_float4(x.c[0], x.c[1], x.c[2], x.c[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!(dbg & 2)) {
+        if (!(kAbl & 2)) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if ((u32)(64 * j) >= R.n)
@@ -331,22 +334,20 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
             }
         }
         if (!phase && R.span) { // park the partial sums: plain stores, same shape as the atomics
-            float *cr = carry + (size_t)R.row * kWide + lane;
+            float *cr = carry + (size_t)((kAbl & 16) ? 0u : R.row) * kWide + lane;
             cr[0] = acc.x, cr[64] = acc.y, cr[128] = acc.z, cr[192] = acc.w;
         } else {
             float *Fg = F + (int64_t)R.gid * D + c0 + lane;
             if (scale_f != 1.0f) // wave-uniform; the .sum() reduction of backproject.py:127 needs no scaling
                 acc.x *= scale_f, acc.y *= scale_f, acc.z *= scale_f, acc.w *= scale_f;
-            if (!(dbg & 1)) {
+            if (!(kAbl & 1) || ((kAbl & 8) && (R.gid & 7u) >= 3u)) {
                 atomicAdd(Fg, acc.x);
                 atomicAdd(Fg + 64, acc.y);
                 atomicAdd(Fg + 128, acc.z);
                 atomicAdd(Fg + 192, acc.w);
-            } else { // ablation: same VMEM count, no atomics
-                __builtin_nontemporal_store(acc.x, Fg);
-                __builtin_nontemporal_store(acc.y, Fg + 64);
-                __builtin_nontemporal_store(acc.z, Fg + 128);
-                __builtin_nontemporal_store(acc.w, Fg + 192);
+            } else { // ablation: same VMEM count, no memory-side cost
+                float *dump = carry + (size_t)(kCarryRows - 1) * kWide + lane;
+                dump[0] = acc.x, dump[64] = acc.y, dump[128] = acc.z, dump[192] = acc.w;
             }
         }
     };
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GWBP_STAMP(ts3);
     __syncthreads();
-#ifdef GWBP_PROFILE
+#ifdef GWBP_STAMPS
     {
         GWBP_STAMP(ts4);
         prof_acc[0] += ts1 - ts0, prof_acc[1] += ts2 - ts1, prof_acc[2] += ts3 - ts2, prof_acc[3] += ts4 - ts3;
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
 #endif
     } // phase
     } // item loop
-#ifdef GWBP_PROFILE
+#ifdef GWBP_STAMPS
     if (lane == 0)
         for (int i = 0; i < 6; ++i)
             atomicAdd(&g_wide_prof[i], prof_acc[i]);
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
 
 } // namespace
 
-#ifdef GWBP_PROFILE
+#ifdef GWBP_STAMPS
 extern "C" int gwbp_profile_read_wide(unsigned long long *out8_host)
 {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -456,7 +457,7 @@ int launch_scatter_wide(const Layout &L, const Ws &W, const ViewDev &V, const Fe
     u32 *queues = W.shards + kShards * 16;
     hipLaunchKernelGGL(k_scatter_wide, dim3(grid), dim3(kThreads), kLdsBytes, s, V, D / kWide, W.tile_offsets,
                        W.half_count[0], W.half_count[1], W.half[0], W.half[1], W.wpool, M, D, scale_f, F, queues, W.carry,
-                       W.counters, profile_knob("GWBP_ABLATE"));
+                       W.counters);
     return check_hip(hipGetLastError(), "scatter_wide launch");
 }
 

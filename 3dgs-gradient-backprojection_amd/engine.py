@@ -56,7 +56,7 @@ class Engine:
 
     def __init__(self, n_gaussians: int, max_width: int, max_height: int, device=None,
                  isect_cap: Optional[int] = None, pair_cap: Optional[int] = None, scatter_workgroups: int = 0,
-                 tight_binning: bool = False, group_scatter: bool = False):
+                 tight_binning: bool = False):
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
             raise GwbpError("Engine needs a HIP device (there is no CPU path)")
@@ -73,11 +73,6 @@ class Engine:
         # because meta["isect_ids"] of the drop-in operator must show gsplat's 3-sigma binning
         self.tight_binning = bool(tight_binning)
         self._halves = False  # the workspace holds the half-tile lists + weight sums of the view blended last
-        # group_scatter: GWBP_FLAG_GROUP_SCATTER -- the workspace also holds the record-group / dense-operand tables of the
-        # block-sparse (matrix-core) scatter kernel and blend_weights fills them (set_group_scatter(False) switches the
-        # kernel off per view without reallocating; an engine built without it cannot switch it on)
-        self.group_capable = bool(group_scatter)
-        self._groups = False  # the workspace holds the record groups + weight sums of the view blended last
         self.stream, self._stream_handle = None, None
         self._alloc()
 
@@ -99,30 +94,14 @@ class Engine:
         else:
             self.caps.flags &= ~_lib.FLAG_NARROW_SCATTER
 
-    def set_group_scatter(self, on: bool) -> None:
-        """GWBP_FLAG_GROUP_SCATTER for the next blend_weights / scatter of this engine (needs Engine(group_scatter=True):
-        the group tables are part of the workspace)."""
-        if on and not self.group_capable:
-            raise GwbpError("this Engine was built without group_scatter=True: its workspace has no group tables")
-        if on:
-            self.caps.flags |= _lib.FLAG_GROUP_SCATTER
-        else:
-            self.caps.flags &= ~_lib.FLAG_GROUP_SCATTER
-
     def _alloc(self):
-        # run-time flags survive a re-allocation (grow); a new engine starts narrow, with the block-sparse scatter on if it is
-        # group-capable
-        run = (self.caps.flags & (_lib.FLAG_FRONT_PRIORITY | _lib.FLAG_NARROW_SCATTER | _lib.FLAG_GROUP_SCATTER)
-               if hasattr(self, "caps") else
-               _lib.FLAG_NARROW_SCATTER | (_lib.FLAG_GROUP_SCATTER if self.group_capable else 0))
+        # run-time flags survive a re-allocation (grow); a new engine starts narrow
+        run = (self.caps.flags & (_lib.FLAG_FRONT_PRIORITY | _lib.FLAG_NARROW_SCATTER)
+               if hasattr(self, "caps") else _lib.FLAG_NARROW_SCATTER)
         base = _lib.FLAG_TIGHT_BINNING if self.tight_binning else 0
-        # the workspace is SIZED with the group tables when the engine is group-capable (they sit behind everything else, so
-        # calls without the flag use the same workspace), whatever the run-time state of the flag
-        size_caps = Caps(self.n, self.isect_cap, self.pair_cap, self.max_w, self.max_h, self.scatter_workgroups,
-                         base | (_lib.FLAG_GROUP_SCATTER if self.group_capable else 0))
-        nbytes = C.c_size_t(0)
-        self._call("gwbp_workspace_size", C.byref(size_caps), C.byref(nbytes))
         self.caps = Caps(self.n, self.isect_cap, self.pair_cap, self.max_w, self.max_h, self.scatter_workgroups, base | run)
+        nbytes = C.c_size_t(0)
+        self._call("gwbp_workspace_size", C.byref(self.caps), C.byref(nbytes))
         self.ws_bytes = int(nbytes.value)
         self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.device)
         off = (-self.ws.data_ptr()) % 256
@@ -136,8 +115,6 @@ class Engine:
             self.isect_cap *= 2
         if stats["overflow"] & 2:
             self.pair_cap = max(2 * self.pair_cap, int(2.5 * stats["n_pairs"] / max(1, views)) + (1 << 16))
-        elif stats["overflow"] & 8:  # group / block tables of the block-sparse scatter: sized from pair_cap
-            self.pair_cap *= 2
         del self.ws
         self._alloc()
 
@@ -198,23 +175,19 @@ class Engine:
         return out
 
     def _wide_requested(self) -> bool:
-        return not (self.caps.flags & (_lib.FLAG_NARROW_SCATTER | _lib.FLAG_GROUP_SCATTER))
-
-    def _groups_requested(self) -> bool:
-        return bool(self.caps.flags & _lib.FLAG_GROUP_SCATTER)
+        return not (self.caps.flags & _lib.FLAG_NARROW_SCATTER)
 
     def blend_weights(self, view, want_alphas=False, d=None, scale_d=1.0):
         """d (optional, float32[N]): also add this view's denominators d[g] += scale_d * sum_p w_g(p) from inside the blend
         (gwbp_blend_weights_d; needs the 256-channel scatter kernel enabled, like accumulate_d)."""
         alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
         self._halves = self._wide_requested()  # k_blend<HALVES> writes the lists only without NARROW_SCATTER
-        self._groups = self._groups_requested()  # k_blend<kGroups> + k_group_sort + k_pack
         if d is not None:
             if d.dtype != torch.float32 or not d.is_cuda or d.shape != (self.n,) or not d.is_contiguous():
                 raise GwbpError("d must be a contiguous float32 HIP tensor [N]")
-            if not (self._halves or self._groups):
-                raise GwbpError("blend_weights(d=...) needs the 256-channel or the block-sparse scatter kernel enabled "
-                                "(set_narrow_scatter(False) / set_group_scatter(True)): a narrow blend takes no weight sums")
+            if not self._halves:
+                raise GwbpError("blend_weights(d=...) needs the 256-channel scatter kernel enabled "
+                                "(set_narrow_scatter(False)): a narrow blend takes no weight sums")
             self._call("gwbp_blend_weights_d", *self._args(), C.byref(view), ptr(alphas), C.c_float(scale_d), ptr(d),
                        self._stream())
             return alphas
@@ -250,7 +223,7 @@ class Engine:
         sy, sx, _, D = self._feat_strides(feats, view)
         self._check_acc(F, d, D)
         alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
-        self._halves = self._groups = False  # the store is empty: no scatter kernel has anything to read
+        self._halves = False  # the store is empty: no scatter kernel has anything to read
         self._call("gwbp_blend_scatter", *self._args(), C.byref(view), ptr(feats), sy, sx, D, C.c_float(scale_f),
                    C.c_float(scale_d), ptr(F), ptr(d), ptr(alphas), self._stream())
         return alphas
@@ -270,8 +243,8 @@ class Engine:
         """d += scale_d * sum_p w from the blend's per-record weight sums (needs a blend with the wide scatter enabled)."""
         if d is None or d.dtype != torch.float32 or not d.is_cuda or d.shape != (self.n,) or not d.is_contiguous():
             raise GwbpError("d must be a contiguous float32 HIP tensor [N]")
-        if not (self._halves or self._groups):
-            raise GwbpError("accumulate_d needs a view blended with the 256-channel or block-sparse scatter kernel enabled "
+        if not self._halves:
+            raise GwbpError("accumulate_d needs a view blended with the 256-channel scatter kernel enabled "
                             "(set_narrow_scatter(False) BEFORE blend_weights): this view's headers hold no weight sums")
         self._call("gwbp_accumulate_d", *self._args(), C.byref(view), C.c_float(scale_d), ptr(d), self._stream())
 
@@ -281,12 +254,11 @@ class Engine:
         upsample="nearest" / "bilinear": feats is a LOW-RESOLUTION map [h,w,D]; the result equals scattering
         F.interpolate(feats, size=(H,W), mode=...) (dino: backproject.py:244-248; lseg: backproject.py:110-112,
         align_corners=False) without building that map -- the interpolation happens while the tile slabs are staged."""
-        if (self._wide_requested() and not self._halves) or (self._groups_requested() and not self._groups):
-            # This view was blended for another scatter kernel than the flags now ask for (no half-tile lists / no record
-            # groups): that kernel would read another view's tables.  Scatter it with the 128-channel vector kernel, which
-            # needs only the headers every blend writes.
+        if self._wide_requested() and not self._halves:
+            # This view was blended WITH GWBP_FLAG_NARROW_SCATTER (no half-tile lists): the 256-channel kernel would read
+            # another view's tables.  Scatter it with the 128-channel kernel, which needs only the headers every blend writes.
             saved = self.caps.flags
-            self.caps.flags = (saved | _lib.FLAG_NARROW_SCATTER) & ~_lib.FLAG_GROUP_SCATTER
+            self.caps.flags = saved | _lib.FLAG_NARROW_SCATTER
             try:
                 return self.scatter(view, feats, F, d, scale_f, scale_d, upsample)
             finally:
@@ -402,7 +374,7 @@ class Engine:
         self._check_acc(F, d, D)
         means, quats = _req(means, "means", (3,)), _req(quats, "quats", (4,))
         scales, opacities = _req(scales, "scales", (3,)), _req(opacities, "opacities")
-        self._halves, self._groups = self._wide_requested(), self._groups_requested()
+        self._halves = self._wide_requested()
         self._call("gwbp_backproject_view", *self._args(), C.byref(view), ptr(means), ptr(quats), ptr(scales),
                                              ptr(opacities), ptr(feats), C.c_int64(sy), C.c_int64(sx),
                                              C.c_int64(sc), D, C.c_float(scale_f), C.c_float(scale_d), ptr(F),

@@ -37,8 +37,8 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="feature maps cycled through (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=8, help="views of the workload the CPU baseline is timed on")
-    ap.add_argument("--scatter", choices=("auto", "groups", "wide", "narrow"), default="auto",
-                    help="scatter kernel: groups = block-sparse on the matrix cores (D %% 128 == 0; opt-in, measured slower), "
+    ap.add_argument("--scatter", choices=("auto", "wide", "narrow"), default="auto",
+                    help="scatter kernel: "
                          "wide / narrow = the 256- / 128-channel vector kernels; auto = wide or narrow from the warm-up views' counters")
     ap.add_argument("--pipe-wgs", type=int, default=None, help="persistent scatter workgroups (tuning)")
     ap.add_argument("--side-prio", type=int, default=-1, help="HIP priority of the front stage's stream")
@@ -124,8 +124,7 @@ def main():
     # feature-map pool, generated on device (seeded), L2-normalised over channels like backproject.py:109
     pool = [syn.make_feature_map(cfg, 1000 * rank + i, device=dev) for i in range(args.pool)]
     tight = not args.exact_binning
-    use_groups = args.scatter == "groups" and D % 128 == 0
-    eng = gsbp_amd.Engine(N, W, H, device=dev, tight_binning=tight, group_scatter=use_groups)
+    eng = gsbp_amd.Engine(N, W, H, device=dev, tight_binning=tight)
     F, d, F_store = gsbp_amd.backproject.alloc_accumulators(N, D, dev, world)
     views = [eng.view(vms[v], K, W, H) for v in my_views]
 
@@ -137,17 +136,15 @@ def main():
         if not st["overflow"]:
             break
         eng.grow(st)
-    allow_wide = args.scatter not in ("narrow", "groups")
+    allow_wide = args.scatter != "narrow"
     if args.serial:
-        eng.set_narrow_scatter(not (D % 256 == 0 and allow_wide and not use_groups))
+        eng.set_narrow_scatter(not (D % 256 == 0 and allow_wide))
         pipe, accum = None, torch.zeros(32, dtype=torch.uint8, device=dev)
     else:
         depth = args.depth or gsbp_amd.backproject.pipeline_depth(N, W, H)
-        more = [gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap, tight_binning=tight,
-                                group_scatter=use_groups)
+        more = [gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap, tight_binning=tight)
                 for _ in range(depth - 1)]
         pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng] + more, scatter_dim=D, allow_wide=allow_wide,
-                                     allow_groups=use_groups,
                                      scatter_workgroups=args.pipe_wgs, side_priority=args.side_prio,
                                      front_priority=None if args.front_prio == "auto" else args.front_prio == "on",
                                      fuse_small=not args.no_fuse_small)
@@ -239,8 +236,6 @@ def main():
         st_w = pipe.stats()
         scatter_choice = pipe.choose_scatter_kernel(*((st_w["n_pairs"], st_w["n_headers"]) if args.scatter == "auto"
                                                       else (None, None)))
-    elif use_groups:
-        scatter_choice = "groups"
     elif D % 256 == 0 and allow_wide:
         scatter_choice = "wide"  # serial schedule: the faster kernel alone (set before the warm-up), no priority
     F_store.zero_()
@@ -328,7 +323,6 @@ def main():
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
         scatter_kernel = (("k_blend_scatter_quarter" if gsbp_amd.Engine.fused_max_dim(W, H) > gsbp_amd.Engine.FUSED_MAX_DIM
                            else "k_blend<kFused>") + " (blend + scatter in one kernel, no weight store)" if fused_small else
-                          "k_scatter_mfma" if scatter_choice == "groups" else
                           "k_scatter_wide" if scatter_choice == "wide" else
                           "k_scatter_full" if (D % 128 == 0 or D <= 64) else "k_scatter")
         traffic, traffic_source, valu_insts = None, None, None
@@ -450,8 +444,6 @@ def check_results(args, gsbp_amd, eng, views, g, pool, encoder, F_rows, d_sum, r
     dG = torch.zeros(n, device=dev)
     asum = torch.zeros((), dtype=torch.float64, device=dev)
     eng.set_narrow_scatter(True)
-    if eng.group_capable:
-        eng.set_group_scatter(False)
     eng.set_front_priority(False)
     for i in range(args.warmup, args.warmup + args.steps):
         eng.project(views[i], *g)

@@ -79,16 +79,8 @@ typedef struct gwbp_caps {
  * the half-tile record lists (15-20 % of its time) when the flag is set, so a view blended WITH the flag must be
  * scattered with it; the other direction (blend without, scatter with) is fine. */
 #define GWBP_FLAG_NARROW_SCATTER 4
-/* Block-sparse scatter on the matrix cores for D % 128 == 0, channel-contiguous full-resolution maps.  gwbp_blend_weights
- * additionally sorts every tile's contributing records by the bounding box of their pixel masks, cuts them into groups of
- * 16 and packs each group into a dense operand table (K-step = 4 pixels of the union of the group's footprints x 16 records,
- * zero where a record has no weight); gwbp_scatter then runs v_mfma_f32_16x16x4_f32 over (16 records x 4 pixels) x (4 pixels x
- * 16 channels) blocks: exact fp32 (a k-ordered fmaf chain; a zero weight adds +-0), every record's sum in ascending pixel order
- * as in the other kernels.  The workspace grows by the group tables (gwbp_workspace_size accounts for it); overflow of their
- * capacity raises gwbp_stats.overflow bit 3.  Takes precedence over the 256-channel vector kernel; maps the kernel does not
- * take (strided channels, index maps, D % 128 != 0) and tiles whose staged pixels are not all finite (0 x NaN) go through the
- * 128-channel vector kernel with identical semantics. */
-#define GWBP_FLAG_GROUP_SCATTER 8
+/* (bit 3 was GWBP_FLAG_GROUP_SCATTER, an experimental block-sparse scatter on the matrix cores: measured slower than the
+ * vector kernels and removed; unknown flag bits are rejected with GWBP_EINVAL.) */
 
 /* Device-resident per-view counters, readable after the stream has drained (gwbp_read_stats). */
 typedef struct gwbp_stats {
@@ -100,9 +92,8 @@ typedef struct gwbp_stats {
     uint32_t overflow;    /* bit0: isect_cap exceeded, bit1: pair_cap exceeded -> results of this view invalid;
                            * bit2: gwbp_scatter / gwbp_accumulate_d asked for the 256-channel kernel on a view that was
                            * blended WITH GWBP_FLAG_NARROW_SCATTER (no half-tile lists / weight sums): that call left
-                           * F and d untouched -- scatter again with the flag set;
-                           * bit3: group / block capacity of GWBP_FLAG_GROUP_SCATTER exceeded -> results invalid, grow pair_cap */
-    uint32_t reserved;    /* what the last blend of this view left: 0 = weight store, 1 = store + half-tile lists, 2 = nothing (gwbp_blend_scatter), 3 = store + record groups */
+                           * F and d untouched -- scatter again with the flag set */
+    uint32_t reserved;    /* what the last blend of this view left: 0 = weight store, 1 = store + half-tile lists, 2 = nothing (gwbp_blend_scatter) */
 } gwbp_stats;
 
 /* Library / build identification ("gfx950;<git-less build tag>"). */

@@ -44,15 +44,10 @@ def test_workspace_size_and_argument_validation():
     # the 256-channel scatter (256 workgroups x 1024 rows x 1 KB)
     expect = 1_000_000 * 60 + 16_000_000 * 112 + 217_088_000 * 8 + 256 * 1024 * 1024
     assert expect < n.value < expect * 1.02
-    # GWBP_FLAG_GROUP_SCATTER: + the record-group tables (8 + 64 + 64 B per group of 16 intersections, 2 groups per tile of
-    # slack) and the dense operand blocks (1040 B per block; pair_cap / 48 + one per group)
-    n2 = C.c_size_t(0)
-    caps_g = _lib.Caps(1_000_000, 16_000_000, 217_088_000, 1600, 1060, 0, _lib.FLAG_GROUP_SCATTER)
-    assert lib.gwbp_workspace_size(C.byref(caps_g), C.byref(n2)) == 0
-    groups = 16_000_000 // 16 + 2 * 6700
-    blocks = 217_088_000 // 3 // 16 + groups
-    extra = groups * 136 + blocks * 1040 + 6700 * 8
-    assert extra < n2.value - n.value < extra * 1.01
+    # unknown flag bits are rejected (bit 3 was the removed GWBP_FLAG_GROUP_SCATTER)
+    caps_g = _lib.Caps(1_000_000, 16_000_000, 217_088_000, 1600, 1060, 0, 8)
+    assert lib.gwbp_workspace_size(C.byref(caps_g), C.byref(C.c_size_t(0))) == -1
+    assert b"unknown caps.flags" in lib.gwbp_last_error_string()
     bad = _lib.Caps(-1, 16, 1 << 20, 64, 64)
     assert lib.gwbp_workspace_size(C.byref(bad), C.byref(n)) == -1
     assert b"caps out of range" in lib.gwbp_last_error_string()

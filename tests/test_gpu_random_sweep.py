@@ -26,11 +26,11 @@ CASES = [
     (8, 3000, 300, 20, 40, 0.03, "padded"), # wide strip
     (9, 1200, 50, 200, 130, 0.05, "chw"),   # tall strip, generic kernel with strides
     (10, 1, 40, 40, 7, 0.30, "hwc"),        # a single Gaussian
-    # the block-sparse (matrix-core) scatter: Engine(group_scatter=True), D % 128 == 0, channel-contiguous maps
-    (11, 2500, 131, 77, 128, 0.03, "groups"),      # edge tiles on both axes
-    (12, 64, 16, 16, 384, 0.50, "groups"),         # one tile, three chunks, screen-filling Gaussians (dense operand rows)
-    (13, 6000, 250, 100, 256, 0.004, "groups"),    # sub-pixel Gaussians: one- and two-pixel records, mostly empty groups
-    (14, 17, 48, 48, 128, 0.15, "groups_padded"),  # one partial group per tile, padded pixel pitch
+    # the 256-channel kernel (set_narrow_scatter(False): half-tile lists, carry rows), D % 256 == 0, channel-contiguous maps
+    (11, 2500, 131, 77, 256, 0.03, "wide"),        # edge tiles on both axes
+    (12, 64, 16, 16, 512, 0.50, "wide"),           # one tile, two chunks, screen-filling Gaussians (128-entry half-tile visits)
+    (13, 6000, 250, 100, 256, 0.004, "wide"),      # sub-pixel Gaussians: one- and two-pixel records, few spanning both halves
+    (14, 17, 48, 48, 256, 0.15, "wide_padded"),    # a handful of records per tile, padded pixel pitch
 ]
 
 
@@ -78,9 +78,10 @@ def _layout(feats, layout, dev):
 def test_random_scene_matches_oracle(case, orc, dev):
     seed, n, W, H, D, s0, layout = case
     means, quats, scales, opac = _scene(seed, n, s0)
-    groups = layout.startswith("groups")
-    eng = gsbp_amd.Engine(n, W, H, device=dev, group_scatter=groups)
-    layout = {"groups": "hwc", "groups_padded": "padded"}.get(layout, layout)
+    wide = layout.startswith("wide")
+    eng = gsbp_amd.Engine(n, W, H, device=dev)
+    eng.set_narrow_scatter(not wide)
+    layout = {"wide": "hwc", "wide_padded": "padded"}.get(layout, layout)
     F = torch.zeros(n, D, device=dev)
     d = torch.zeros(n, device=dev)
     Fr = np.zeros((n, D), np.float64)
@@ -96,7 +97,7 @@ def test_random_scene_matches_oracle(case, orc, dev):
         eng.backproject_view(eng.view(vm, K, W, H), *g_dev, _layout(feats, layout, dev), F, d)
         st = eng.stats()
         info = orc.backproject_view(*g_np, vm.numpy(), K.numpy(), W, H, feats.numpy(), Fr, dr)
-        assert st["overflow"] == 0 and st["blend_kind"] == (3 if groups else 0)
+        assert st["overflow"] == 0 and st["blend_kind"] == (1 if wide else 0)
         assert (st["n_pairs"], st["n_isect"], st["n_visible"]) == (info["n_pairs"], info["n_isect"], info["n_vis"])
         total_pairs += info["n_pairs"]
     assert rel_row_err(F.cpu().numpy(), Fr) <= 1e-4

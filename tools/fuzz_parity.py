@@ -21,7 +21,6 @@ orc.build()
 DIMS = [1, 3, 4, 7, 8, 12, 16, 17, 32, 40, 64, 65, 100, 128, 130, 256, 384, 512, 768]
 bad = 0
 n_fused = 0
-n_groups = 0
 t0 = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
@@ -66,9 +65,7 @@ for case in range(n_cases):
         fd = buf[:, :fd.shape[1], :D]
     wide = bool(rng.integers(0, 2))
     tight = bool(rng.integers(0, 2))
-    groups = D % 128 == 0 and bool(rng.integers(0, 2))  # the block-sparse (matrix-core) scatter; maps it does not take
-    n_groups += int(groups)                              # (strided channels, upsampling) fall back inside the library
-    eng = gsbp_amd.Engine(n, W, H, device=dev, tight_binning=tight, isect_cap=1 << 21, pair_cap=1 << 24, group_scatter=groups)
+    eng = gsbp_amd.Engine(n, W, H, device=dev, tight_binning=tight, isect_cap=1 << 21, pair_cap=1 << 24)
     eng.set_narrow_scatter(not wide)
     view = eng.view(vm, K, W, H)
     fused = up is None and bool(rng.integers(0, 2)) and gsbp_amd.Engine.can_blend_scatter(fd)
@@ -103,5 +100,5 @@ for case in range(n_cases):
         bad += 1
         print(f"FAIL case {seed0 + case}: N={n} {W}x{H} D={D} s0={s0:.4f} {layout} up={up} wide={wide} tight={tight} fused={fused} "
               f"pairs {st['n_pairs']}/{info['n_pairs']} eF={eF:.2e} ed={ed:.2e} overflow={st['overflow']}", flush=True)
-print(f"{n_cases} cases ({n_fused} through the fused blend+scatter kernel, {n_groups} with the block-sparse scatter enabled), {bad} failures, {time.time() - t0:.0f} s")
+print(f"{n_cases} cases ({n_fused} through the fused blend+scatter kernel), {bad} failures, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)

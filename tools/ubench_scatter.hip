@@ -262,6 +262,21 @@ __global__ __launch_bounds__(1024) void k(int iters, const float *__restrict__ w
                     acc2.x = __builtin_fmaf(w, g[j].z, acc2.x);
                     acc2.y = __builtin_fmaf(w, g[j].w, acc2.y);
                 }
+            } else if (MODE == 15) {
+                // mode 5 with four v_fma_f32 (SGPR weight) instead of two v_pk_fma_f32: same lanes x flops, half the SGPRs per weight
+                float4 g[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int p = rl_i(pv, 8 * b + j) & 31;
+                    g[j] = *(const float4 *)(slab + ((p << 10) + lane * 16));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float w = rl_f(wv, 8 * b + j);
+                    asm volatile("v_fma_f32 %0, %4, %5, %0\n\tv_fma_f32 %1, %4, %6, %1\n\tv_fma_f32 %2, %4, %7, %2\n\tv_fma_f32 %3, %4, %8, %3"
+                                 : "+v"(acc.x), "+v"(acc.y), "+v"(acc2.x), "+v"(acc2.y)
+                                 : "s"(w), "v"(g[j].x), "v"(g[j].y), "v"(g[j].z), "v"(g[j].w));
+                }
             } else if (MODE == 5) {
                 float4 g[8];
 #pragma unroll
@@ -340,6 +355,7 @@ int main()
     run<5>("5 readlane x2 + add + b128 + 2pkfma", iters, w, p, out, 2.0);
     run<6>("6 LDS bcast b64/pair + add+b64+pkfma", iters, w, p, out);
     run<7>("7 LDS bcast b128/2pairs + ...", iters, w, p, out);
+    run<15>("15 mode 5 with 4 v_fma_f32 per pair", iters, w, p, out, 2.0);
     run<10>("10 mode 5, 2 batches of 4 in flight", iters, w, p, out, 2.0);
     run<11>("11 mode 5, 2 batches of 8 in flight", iters, w, p, out, 2.0);
     run<14>("14 mode 5, pixel by scalar bit scan", iters, w, p, out, 2.0);
