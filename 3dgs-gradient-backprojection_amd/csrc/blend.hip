@@ -27,7 +27,8 @@ constexpr int kBatch = 64;
 
 // What a contributing record turns into.
 //   kStore:  entries {w, pixel} + Header in the weight store (read by k_scatter_full / k_scatter / k_render_*)
-//   kHalves: the same plus the half-tile record lists and weight sums the 256-channel scatter kernel reads
+//   kHalves: the same plus the record's weight sum in its header (+ d[gid]): what gwbp_scatter's 256-channel path asks for
+//            (k_scatter_wide builds its half-tile visit lists itself, from these headers)
 //   kFused:  NO store: the record's sums  F[gid, :D] += sum_p w f[p, :],  d[gid] += sum_p w  are formed right here from
 //            the tile's pixels held in registers (D <= 16: 4 pixels x 16 channels = 64 VGPRs per lane) and added to F / d
 //            with one atomic instruction -- the small-D variants (backproject_compressed.py:127-165: D = 16) then need
@@ -154,8 +155,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                                               Counters *__restrict__ ctr, Header *__restrict__ headers,
                                               u32 *__restrict__ hdr_count, WPair *__restrict__ wpool, u32 pair_cap,
                                               u32 *__restrict__ shards, const u32 *__restrict__ tile_order, float *__restrict__ alphas,
-                                              HalfHdr *__restrict__ half_a, HalfHdr *__restrict__ half_b,
-                                              u32 *__restrict__ half_cnt_a, u32 *__restrict__ half_cnt_b, int dbg_arg, int prio,
+                                              int dbg_arg, int prio,
                                               float *__restrict__ d_out, float scale_d, FusedArgs fu)
 {
 #ifdef GWBP_PROFILE
@@ -164,7 +164,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     constexpr int dbg = 0;   // the product kernel does not even contain the ablation branches
     (void)dbg_arg;
 #endif
-    constexpr bool HALVES = MODE == kHalves;
     constexpr bool WSUM = MODE == kHalves; // the record's weight sum in its header (+ d[gid] right here)
     front_priority(prio);
     __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
@@ -198,7 +197,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         Tout[q] = 1.0f;
     }
     u32 page_pos = 0, page_left = 0, npairs = 0, hdr_n = 0; // wave-uniform
-    u32 n_top = 0, n_bot = 0;                               // records with entries in tile rows 0..7 / 8..15
     bool dead = false;                                     // wave-uniform: pool exhausted
 
     // kFused: the lane's four pixels, kFusedCh channels each, stay in registers for the whole tile (pixels outside the
@@ -390,8 +388,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     z.w = 0.f, z.pix = 0u;
                     wpool[page_pos + total + lane] = z;
                 }
-                // only the 256-channel scatter kernel wants the record's weight sum and the half-tile lists; computing them
-                // regardless cost the blend 15-20 % (and 7 VGPRs), hence the template parameter
+                // only the 256-channel scatter path wants the record's weight sum (its visit loop has no room for d), hence the
+                // template parameter
                 float wsum = 0.f; // the record's share of d[gid] (k_accum_d)
                 if constexpr (WSUM) {
                     float wl = 0.f;
@@ -413,23 +411,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         if (d_out) // (spelled as the instruction: hipcc wraps a single-lane atomicAdd in its wave-aggregation code)
                             asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(d_out + h.gid), "v"(wsum * scale_d) : "memory");
                     }
-                    // the same record as (up to) two half-tile visits for k_scatter_wide
-                    const u32 ct = HALVES ? cnt[0] + cnt[1] : 0u, cb = HALVES ? cnt[2] + cnt[3] : 0u;
-                    const u32 span = (ct != 0 && cb != 0 && n_top < (u32)kCarryRows) ? 0x100u : 0u;
-                    if (ct) {
-                        HalfHdr t;
-                        t.gid = h.gid, t.off = page_pos, t.n_span = ct | span, t.row = n_top;
-                        half_a[beg + n_top] = t;
-                    }
-                    if (cb) {
-                        HalfHdr t;
-                        t.gid = h.gid, t.off = page_pos + base[2], t.n_span = cb | span, t.row = n_top;
-                        half_b[beg + n_bot] = t;
-                    }
-                }
-                if constexpr (HALVES) {
-                    n_top += (cnt[0] + cnt[1]) ? 1u : 0u;
-                    n_bot += (cnt[2] + cnt[3]) ? 1u : 0u;
                 }
                 ++hdr_n;
             }
@@ -442,8 +423,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         if (MODE == kFused && blockIdx.x == 0)
             ctr->blend_kind = kBlendFused; // (no k_pool_stats launch behind the fused kernel: the pool is untouched)
         hdr_count[tile] = MODE == kFused ? 0u : hdr_n; // kFused: the store stays empty
-        if constexpr (HALVES)
-            half_cnt_a[tile] = n_top, half_cnt_b[tile] = n_bot;
         if (hdr_n)
             atomicAdd(&ctr->n_headers, hdr_n);
         if (npairs)
@@ -683,7 +662,7 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
 #define GWBP_BLEND(H)                                                                                                 \
     hipLaunchKernelGGL(k_blend<H>, dim3(n_tiles), dim3(64), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d,  \
                        W.counters, W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, W.tile_order, alphas,  \
-                       W.half[0], W.half[1], W.half_count[0], W.half_count[1], ablate, prio, d, scale_d, fu)
+                       ablate, prio, d, scale_d, fu)
     if (fused && n_tiles <= kQuarterMaxTiles) {
 #define GWBP_QUARTER(C)                                                                                               \
     hipLaunchKernelGGL(k_blend_scatter_quarter<C>, dim3(4 * n_tiles), dim3(64), 0, s, V, W.tile_offsets, W.vals[fin], W.g2d, \
@@ -697,8 +676,7 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
         GWBP_BLEND(kFused);
     else if (L.flags & GWBP_FLAG_NARROW_SCATTER)
         GWBP_BLEND(kStore);
-    else // (the half-tile lists as a streaming kernel of their own behind a list-less blend -- 0.65 + 0.05 ms alone instead of
-         // 0.80 -- were measured 0.3 % SLOWER in the pipeline, A/B on one box: 3.852-3.870 against 3.846-3.847 ms/view)
+    else
         GWBP_BLEND(kHalves);
 #undef GWBP_BLEND
     if (!fused)

@@ -133,12 +133,9 @@ int make_layout(const gwbp_caps *c, Layout *L)
     L->tile_order = take((size_t)L->max_tiles * sizeof(u32));
     L->hdr_count = take((size_t)L->max_tiles * sizeof(u32));
     L->headers = take((size_t)L->isect_cap * sizeof(Header));
-    for (int i = 0; i < 2; ++i) {
-        L->half[i] = take((size_t)L->isect_cap * sizeof(HalfHdr));
-        L->half_count[i] = take((size_t)L->max_tiles * sizeof(u32));
-    }
     L->carry = take((size_t)kCarryWgs * kCarryRows * 256 * sizeof(float));
-    L->wpool = take((size_t)L->pair_cap * sizeof(WPair));
+    L->wpool = take((size_t)L->pair_cap * sizeof(WPair) + 1024); // + 128 entries: k_scatter_wide loads 128 entries per visit
+                                                                  // without clamping to the visit's length
     L->total = o;
     return GWBP_OK;
 }
@@ -175,10 +172,6 @@ int bind_workspace(const gwbp_caps *caps, void *ws, size_t bytes, Layout *L, Ws 
     W->tile_order = reinterpret_cast<u32 *>(b + L->tile_order);
     W->hdr_count = reinterpret_cast<u32 *>(b + L->hdr_count);
     W->headers = reinterpret_cast<Header *>(b + L->headers);
-    for (int i = 0; i < 2; ++i) {
-        W->half[i] = reinterpret_cast<HalfHdr *>(b + L->half[i]);
-        W->half_count[i] = reinterpret_cast<u32 *>(b + L->half_count[i]);
-    }
     W->carry = reinterpret_cast<float *>(b + L->carry);
     W->wpool = reinterpret_cast<WPair *>(b + L->wpool);
     return GWBP_OK;

@@ -55,17 +55,7 @@ struct __attribute__((aligned(64))) Header {
 };
 static_assert(sizeof(Header) == 64, "header is one 64-B line");
 
-// The same records once more, split into the tile's TOP half (rows 0..7 = quarters 0,1) and BOTTOM half (quarters 2,3)
-// for k_scatter_wide, which stages half-tile slabs of 256 channels: list A / list B of a tile hold only the records
-// that have entries in that half (so no wave ever claims an empty visit).  A record present in both halves carries its
-// partial sums from the top to the bottom pass through row `row` of the workgroup's carry buffer.
-struct __attribute__((aligned(16))) HalfHdr {
-    u32 gid;
-    u32 off;    // first entry of this half in the weight store (the half's entries are contiguous)
-    u32 n_span; // entries in this half (1..128) | spans-both-halves-and-has-a-carry-row << 8
-    u32 row;    // carry row: the record's index in list A of its tile (valid when the span bit is set)
-};
-constexpr int kCarryRows = 1024; // carry rows per scatter workgroup; records of list A beyond it are flushed per half
+constexpr int kCarryRows = 1024; // carry rows per scatter workgroup; a tile's records beyond it are flushed per half
 constexpr int kCarryWgs = 256;   // scatter workgroups that own a carry slice (persistent grid: one per CU)
 
 // Mirrors gwbp_stats (include/gwbp.h) field for field.
@@ -76,7 +66,7 @@ struct Counters {
     u32 n_headers;
     u32 pool_head;
     u32 overflow;
-    u32 blend_kind; // gwbp_stats::reserved: kBlendHalves once k_blend<true> has written the half-tile lists of THIS view
+    u32 blend_kind; // gwbp_stats::reserved: kBlendHalves once k_blend<kHalves> has written THIS view's weight sums
 };
 constexpr u32 kBlendHalves = 1u;
 constexpr u32 kBlendFused = 2u; // gwbp_blend_scatter: the view was blended AND scattered, its weight store is empty
@@ -86,7 +76,7 @@ static_assert(sizeof(Counters) == sizeof(gwbp_stats), "Counters must mirror gwbp
 struct Layout {
     size_t total;
     size_t counters, shards, g2d, rect, touched, blocksums, dkeys[2], dvals[2], keys[2], vals[2], hist, digit_total, tile_offsets, tile_order, hdr_count,
-        headers, half[2], half_count[2], carry, wpool;
+        headers, carry, wpool;
     int64_t n, isect_cap, pair_cap;
     int max_tiles, n_scan_blocks, n_sort_blocks, scatter_wgs, flags;
 };
@@ -107,8 +97,6 @@ struct Ws {
     u32 *tile_order; // tiles by descending list length (heavy tiles start first in k_blend)
     u32 *hdr_count;
     Header *headers;
-    HalfHdr *half[2];    // [0] top-half records, [1] bottom-half records, indexed like headers (tile_offsets[t] + i)
-    u32 *half_count[2];  // per tile
     float *carry;        // kCarryWgs x kCarryRows x 256 floats
     WPair *wpool;
 };
