@@ -373,13 +373,21 @@ class ViewPipeline:
 OVERFLOW_CHECK_EVERY = 32
 
 
-def pipeline_depth(n_gaussians: int, width: int, height: int) -> int:
-    """Workspaces (views in flight) of the ViewPipeline.  2 for large scenes: the scatter kernel is the long stage and one
-    front beside it is all the chip has room for (C2, C4, C5: a third workspace changes nothing).  4 -- three front stages
-    in flight on three side streams -- for small scenes, where a view is ~35 dependent launches of 5-20 us each and the
-    chain, not the chip, is the limit (C1: 0.49 -> 0.19 ms/view; 5 and more lose again: the streams start sharing
-    hardware queues)."""
-    return 4 if (n_gaussians <= 250_000 and width * height <= 1_000_000) else 2
+def pipeline_depth(n_gaussians: int, width: int, height: int, dim: Optional[int] = None) -> int:
+    """Workspaces (views in flight) of the ViewPipeline.
+    Small scenes: 4 -- three front stages in flight on three side streams: a view is ~35 dependent launches of 5-20 us each
+    and the chain, not the chip, is the limit (C1: 0.49 -> 0.19 ms/view; 5 and more lose again: the streams start sharing
+    hardware queues).
+    Large scenes: 3.  Since round 4 the 256-channel scatter kernel prefetches its next slab under the tail of the running
+    pass, which leaves the ONE front stage beside it too few idle slots to keep up (C2 at depth 2: front 3.82 ms against a
+    3.70 ms scatter); with two fronts in flight the scatter kernel is the long stage again (3.91 -> 3.71 ms/view; C4
+    10.15 -> 10.02; a fourth workspace adds nothing).  Maps narrow enough for the fused blend + scatter kernel (`dim` <= 16 on
+    large images, the compressed variant) keep 2: that kernel's schedule is built for two workspaces (C5: 1.47 against 1.98)."""
+    if n_gaussians <= 250_000 and width * height <= 1_000_000:
+        return 4
+    if dim is not None and dim <= Engine.fused_max_dim(width, height):
+        return 2
+    return 3
 
 
 def create_feature_field(means, quats, scales, opacities, viewmats, K, width: int, height: int,
@@ -416,7 +424,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     no event is recorded (a third of the host time per view there); only for functions that allocate and produce their
     output entirely on torch's current stream at call time.
     pipeline: overlap the front stages of the next view(s) with the scatter of view v (ViewPipeline); True = depth chosen by
-    pipeline_depth(N, width, height), an int >= 2 = that many workspaces, False = one stream.
+    pipeline_depth(N, width, height, dim_out), an int >= 2 = that many workspaces, False = one stream.
     gather: under a process group, all-gather the finalised row blocks so that every rank returns the whole [N, dim_out]
     field; False returns this rank's block only (rows row0 .. of `return_partials`' stats["row0"]).
     return_partials: also return (F_rows, d, stats): the summed, un-normalised accumulators (this rank's row block of F,
@@ -442,7 +450,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
         eng = engine or Engine(n, width, height, device=dev, tight_binning=True)  # same F and d, shorter tile lists
         for attempt in range(6):  # a capacity overflow invalidates the accumulators: grow the workspace, start over
             if pipeline and len(my_views) > 1:
-                depth = pipeline_depth(n, width, height) if pipeline is True else max(2, int(pipeline))
+                depth = pipeline_depth(n, width, height, d_out) if pipeline is True else max(2, int(pipeline))
                 pipe = ViewPipeline(n, width, height, dev, scatter_dim=d_out,
                                     allow_wide=allow_wide, fuse_small=fuse_small and not (fuse_encoder and encoder is not None),
                                     engines=[eng] + [Engine(n, width, height, device=dev, tight_binning=eng.tight_binning,

@@ -144,6 +144,17 @@ __device__ __forceinline__ void atomic_f(u32 voff, float v, u64 base)
 {
     asm volatile("global_atomic_add_f32 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
 }
+// a wave-uniform dword through the vector path (every lane reads the same address): unlike a scalar load it does not force
+// the loop's lgkmcnt waits to zero, and unlike a compiler-issued load it is not waited for behind the visit loop's atomics
+__device__ __forceinline__ void load_u(u32 &dst, u32 voff, u64 base)
+{
+    asm volatile("global_load_dword %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_info(u32 &a, u32 &b)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_land(Land &x)
 {
@@ -221,40 +232,80 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
 #ifdef GWBP_STAMPS
     unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
 #endif
-    u32 round = 0; // parity selects the claim counter / visit count in use
-    for (u32 k = 0;; ++k) {
-    const u32 item = uniform(ctl[4 + (k & 1u)]); // wave-uniform by construction: keep every derived address scalar
-    if (item >= n_items)
-        break;
-    const int chunk = (int)(item % (u32)n_chunks);
-    const int tile = (int)((item / (u32)n_chunks) * 8u + xcls);
-    const int tx = tile % V.tile_w, ty = tile / V.tile_w;
-    const int c0 = chunk * kWide;
-    const u32 n_rec = uniform(hdr_count[tile]);
-    const Header *hbase = headers + tile_offsets[tile];
-    const u64 f_chunk = reinterpret_cast<u64>(F + c0);
-
-#pragma unroll 1
-    for (int phase = 0; phase < 2; ++phase) {
-#pragma unroll 1
-    for (u32 rbase = 0; rbase == 0 || rbase < n_rec; rbase += (u32)kVisCap, ++round) {
-    GWBP_STAMP(ts0);
-    const u32 par = round & 1u;
-    if (threadIdx.x == 0) {
-        ctl[par ^ 1u] = 0, ctl[2u + (par ^ 1u)] = 0; // the next round's counters (last used one barrier ago)
-        if (phase == 0 && rbase == 0)
-            ctl[4 + ((k + 1u) & 1u)] = atomicAdd(queue, 1u); // claim the next item under the slab loads
-    }
-    // (a) this round's records -> header loads in flight
-    const u32 rec = rbase + threadIdx.x;
-    const bool has = rec < n_rec;
+    // ---- the round in progress (everything here is wave-uniform) ----------------------------------------------------------
+    // A round = one pass of an item over up to kVisCap records: (item, phase, rbase).  The loads a round starts with -- its
+    // records' headers and, in the first round of a pass, the half-tile slab -- are issued at the END of the previous round,
+    // by every wave as it runs out of visits, so that they fly under the other waves' last visits and the barrier.
+    u32 k = 0;                       // items this workgroup has started
+    u32 item = uniform(ctl[4]);
+    int phase = 0;
+    u32 rbase = 0;
+    int tile = 0, tx = 0, ty = 0, c0 = 0;
+    u32 n_rec = 0;
+    const Header *hbase = headers;
+    u64 f_chunk = 0;
+    auto set_item = [&](u32 it, u32 nrec, u32 toff) __attribute__((always_inline)) {
+        const int chunk = (int)(it % (u32)n_chunks);
+        tile = (int)((it / (u32)n_chunks) * 8u + xcls);
+        tx = tile % V.tile_w, ty = tile / V.tile_w;
+        c0 = chunk * kWide;
+        n_rec = nrec;
+        hbase = headers + toff;
+        f_chunk = reinterpret_cast<u64>(F + c0);
+    };
+    auto tile_of = [&](u32 it) __attribute__((always_inline)) -> u32 { return (it / (u32)n_chunks) * 8u + xcls; };
+    // registers that carry a round's loads across the end-of-round barrier
     uint4 h0 = make_uint4(0u, 0u, 0u, 0u);
     uint2 h1 = make_uint2(0u, 0u);
-    if (has) {
-        h0 = *reinterpret_cast<const uint4 *>(hbase + rec);     // gid, woff[0..2]
-        h1 = reinterpret_cast<const uint2 *>(hbase + rec)[2];   // woff[3], counts
+    constexpr int kUnits = kHalfPix / (kThreads / 64); // 8 pixels per wave
+    float4 vals[kUnits];
+    u32 next_claim = 0; // thread 0: the item after this one, claimed when this one was started
+    const int wv = (int)uniform(threadIdx.x >> 6);
+    auto stage_issue = [&]() __attribute__((always_inline)) {
+        // (a) this round's records
+        const u32 rec = rbase + threadIdx.x;
+        h0 = make_uint4(0u, 0u, 0u, 0u), h1 = make_uint2(0u, 0u);
+        if (rec < n_rec) {
+            h0 = *reinterpret_cast<const uint4 *>(hbase + rec);   // gid, woff[0..2]
+            h1 = reinterpret_cast<const uint2 *>(hbase + rec)[2]; // woff[3], counts
+        }
+        // (b) 128 px x 256 ch (first round of a pass only; a second round reuses the slab): wave v stages tile column v of the
+        // eight tile rows of this half, one pixel = 4 coalesced dword loads (one per 64-channel group) + one ds_write_b128 per
+        // lane.  Pixel addresses are wave-uniform (scalar registers; with index maps scalar loads), the per-lane part is lane * 4.
+        if (!BILINEAR && !(kAbl & 4) && n_rec != 0 && rbase == 0) {
+            // pixels past the image edge are never referenced by an entry: load a clamped (valid) address
+            const int ix = min(tx * kTile + wv, V.W - 1);
+            const int64_t xoff = (int64_t)(M.xmap ? M.xmap[ix] : ix) * M.fs_x + c0;
+            const float *rows[kUnits];
+#pragma unroll
+            for (int u = 0; u < kUnits; ++u) { // (row offsets first: with an index map they are loads themselves)
+                const int iy = min(ty * kTile + phase * (kTile / 2) + u, V.H - 1);
+                rows[u] = feats + ((int64_t)(M.ymap ? M.ymap[iy] : iy) * M.fs_y + xoff);
+            }
+#pragma unroll
+            for (int u = 0; u < kUnits; ++u) {
+                const float *src = rows[u] + lane;
+                vals[u] = make_float4(src[0], src[64], src[128], src[192]);
+            }
+        }
+    };
+    if (item < n_items) {
+    set_item(item, uniform(hdr_count[tile_of(item)]), uniform(tile_offsets[tile_of(item)]));
+    if (threadIdx.x == 0)
+        next_claim = atomicAdd(queue, 1u);
+    stage_issue();
+#pragma unroll 1
+    for (u32 round = 0;; ++round) { // parity selects the claim counter / visit count in use
+    GWBP_STAMP(ts0);
+    __syncthreads(); // the previous round's visits are over: slab, table and the other parity's counters are free
+    const u32 par = round & 1u;
+    if (threadIdx.x == 0) {
+        ctl[par ^ 1u] = 0, ctl[2u + (par ^ 1u)] = 0; // the next round's counters
+        if (phase == 0 && rbase == 0)
+            ctl[4 + ((k + 1u) & 1u)] = next_claim; // (claimed a round ago: its round trip is over)
     }
-    // (b) slab loads (first round of a pass only; a second round reuses the slab)
+    const u32 rec = rbase + threadIdx.x;
+    const bool has = rec < n_rec;
     const bool stage = !(kAbl & 4) && n_rec != 0 && rbase == 0;
     if (BILINEAR && stage) {
         // Bilinear low-resolution map (backproject.py:110-112 folded in): every slab value is the blend of four texels
@@ -281,29 +332,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
                 *reinterpret_cast<float4 *>(lds + (idx >> 6) * kWide + 4 * lane) = make_float4(r[0], r[1], r[2], r[3]);
         }
     }
-    // 128 px x 256 ch: wave v stages tile column (v & 15) of the eight tile rows of this half, one pixel = 4 coalesced dword loads
-    // (one per 64-channel group) + one ds_write_b128 per lane.  Pixel addresses are wave-uniform (scalar registers; with
-    // index maps scalar loads), the per-lane part is lane * 4 B.
-    constexpr int kUnits = kHalfPix / (kThreads / 64); // 8 pixels per wave
-    float4 vals[kUnits];
     const bool stage_plain = !BILINEAR && stage;
-    const int wv = (int)uniform(threadIdx.x >> 6);
-    if (stage_plain) {
-        // pixels past the image edge are never referenced by an entry: load a clamped (valid) address
-        const int ix = min(tx * kTile + wv, V.W - 1);
-        const int64_t xoff = (int64_t)(M.xmap ? M.xmap[ix] : ix) * M.fs_x + c0;
-        const float *rows[kUnits];
-#pragma unroll
-        for (int u = 0; u < kUnits; ++u) { // (row offsets first: with an index map they are loads themselves)
-            const int iy = min(ty * kTile + phase * (kTile / 2) + u, V.H - 1);
-            rows[u] = feats + ((int64_t)(M.ymap ? M.ymap[iy] : iy) * M.fs_y + xoff);
-        }
-#pragma unroll
-        for (int u = 0; u < kUnits; ++u) {
-            const float *src = rows[u] + lane;
-            vals[u] = make_float4(src[0], src[64], src[128], src[192]);
-        }
-    }
     // (a') the visit table: records with entries in this half, compacted wave by wave (their order does not matter)
     {
         const u32 cnt = h1.y;
@@ -333,6 +362,18 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
 #endif
     const u32 nv = uniform(ctl[2u + par]);
     const u32 claim_addr = kCtlOff + 4u * par;
+    const u64 f_base = uniform64(f_chunk); // (a loop-carried value: hipcc does not prove it scalar, and an "s" operand must be)
+    // The next item's tile facts (record count, first header), fetched under this pass's visits: two loads of the asm-counted
+    // kind, older than every visit's operations, so the counted waits never see them.
+    // (Issued in every round, unconditionally: a conditional asm load makes hipcc copy its destination behind the branch --
+    // before the data has landed.)
+    u32 nx_nrec = 0, nx_toff = 0;
+    const u32 nx_item = uniform(ctl[4 + ((k + 1u) & 1u)]);
+    {
+        const u32 t = tile_of(min(nx_item, n_items - 1u));
+        load_u(nx_nrec, 0u, reinterpret_cast<u64>(hdr_count + t));
+        load_u(nx_toff, 0u, reinterpret_cast<u64>(tile_offsets + t));
+    }
 
     // dynamic LDS starts at address 0 (no static __shared__ in this kernel): slab row r lives at byte r * 1024
     const u32 row_base = (u32)(lane * 16) - (phase ? (u32)(kHalfPix << 10) : 0u);
@@ -409,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     // Visit pipeline.  `cur` is processed, the entries of `nxt` are in flight into the landing buffer (loaded at the top of
     // the previous visit), the descriptor of the visit after `nxt` is read from the table during this visit, its index
     // claimed at the top of it.
-    auto visits = [&](auto bottom) __attribute__((always_inline)) {
+    auto visits = [&](auto bottom) __attribute__((always_inline)) -> bool {
         Land L = {{{0.f, 0u}, {0.f, 0u}}, {0.f, 0.f, 0.f, 0.f}};
         u32 cl = 0;
         u32x4_t tn = {0u, 0u, 0u, 0u};
@@ -478,7 +519,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
                     if (scale_f != 1.0f) // wave-uniform; the .sum() reduction of backproject.py:127 needs no scaling
                         acc_lo *= scale_f, acc_hi *= scale_f;
                     if (!(kAbl & 1) || ((kAbl & 8) && (cur.gid & 7u) >= 3u)) {
-                        const u64 fb = sbase(f_chunk + (u64)cur.gid * (u64)((u32)D * 4u));
+                        const u64 fb = sbase(f_base + (u64)cur.gid * (u64)((u32)D * 4u));
                         atomic_f<0>(lane4, acc_lo.x, fb);
                         atomic_f<256>(lane4, acc_lo.y, fb);
                         atomic_f<512>(lane4, acc_hi.x, fb);
@@ -498,31 +539,47 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
                 nxt = decode(make_uint4(tn.x, tn.y, tn.z, tn.w));
                 h_nxt = h_n2;
             }
-            wait_land<0>(L); // the last prefetch still targets the landing registers
+            wait_land<kFlush>(L); // the last prefetch still targets the landing registers (the last flush may stay in flight)
+            return true;
         }
+        return false;
     };
-    if (nv != 0) {
-        if (phase)
-            visits(std::true_type{});
-        else
-            visits(std::false_type{});
-    }
-    // Drain: (1) the carry rows parked in the top pass must be in L2 before any wave of the bottom pass loads them,
-    // (2) the slab and the table are about to be overwritten (LDS reads are complete: every visit waited for its own).
+    bool ran = false;
+    if (nv != 0)
+        ran = phase ? visits(std::true_type{}) : visits(std::false_type{});
+    // No drain: a visit leaves at most its own flush in flight.  The carry rows parked in the top pass are in L2 before any
+    // wave of the bottom pass loads them, because every wave waits for the header loads it issues BELOW (in-order vmcnt: all
+    // its older stores are complete by then) before it reaches the barrier in front of the next round's visits; LDS reads are
+    // complete (every visit waited for its own).
     GWBP_STAMP(ts2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (a wave that ran visits has at most its last flush in flight; one that did not may have to wait for older atomics)
+    if (ran)
+        wait_info<kFlush>(nx_nrec, nx_toff);
+    else
+        wait_info<0>(nx_nrec, nx_toff);
     GWBP_STAMP(ts3);
-    __syncthreads();
 #ifdef GWBP_STAMPS
-    {
-        GWBP_STAMP(ts4);
-        prof_acc[0] += ts1 - ts0, prof_acc[1] += ts2 - ts1, prof_acc[2] += ts3 - ts2, prof_acc[3] += ts4 - ts3;
-        prof_acc[4] += 1ull, prof_acc[5] += (unsigned long long)n_vis_prof;
-    }
+    prof_acc[0] += ts1 - ts0, prof_acc[1] += ts2 - ts1, prof_acc[2] += ts3 - ts2;
+    prof_acc[4] += 1ull, prof_acc[5] += (unsigned long long)n_vis_prof;
 #endif
+    // ---- the next round, and its loads --------------------------------------------------------------------------------------
+    if (rbase + (u32)kVisCap < n_rec) {
+        rbase += (u32)kVisCap; // more records of this half: same slab
+    } else if (phase == 0) {
+        phase = 1, rbase = 0;
+    } else {
+        ++k;
+        item = nx_item;
+        if (item >= n_items)
+            break;
+        set_item(item, uniform(nx_nrec), uniform(nx_toff));
+        phase = 0, rbase = 0;
+        if (threadIdx.x == 0)
+            next_claim = atomicAdd(queue, 1u);
+    }
+    stage_issue();
     } // round
-    } // phase
-    } // item loop
+    } // any item at all
 #ifdef GWBP_STAMPS
     if (lane == 0)
         for (int i = 0; i < 6; ++i)

@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--one-device", action="store_true",
                     help="every rank uses cuda:0 (checks the N > 1 bookkeeping on a one-GPU box together with --dist-backend gloo)")
     ap.add_argument("--depth", type=int, default=0,
-                    help="workspaces / views in flight of the pipeline (0 = auto: 4 for small scenes, else 2)")
+                    help="workspaces / views in flight of the pipeline (0 = auto: 4 for small scenes, 2 for narrow maps on large ones, else 3)")
     ap.add_argument("--enc-wgs-per-cu", type=float, default=None, help="C5 tuning: encoder workgroups per CU in the pipeline")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run result check (the `checked` object)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
@@ -141,7 +141,7 @@ def main():
         eng.set_narrow_scatter(not (D % 256 == 0 and allow_wide))
         pipe, accum = None, torch.zeros(32, dtype=torch.uint8, device=dev)
     else:
-        depth = args.depth or gsbp_amd.backproject.pipeline_depth(N, W, H)
+        depth = args.depth or gsbp_amd.backproject.pipeline_depth(N, W, H, D)
         more = [gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap, tight_binning=tight)
                 for _ in range(depth - 1)]
         pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng] + more, scatter_dim=D, allow_wide=allow_wide,
