@@ -44,7 +44,8 @@ namespace gwbp {
 
 #ifdef GWBP_STAMPS
 // In-kernel stamps (make PROFILE=1 only, tools/stamp_scatter.py): shader cycles summed over the waves of all workgroups,
-// [0] table + slab staging incl. its barrier, [1] visit loop, [2] drain, [3] end-of-round barrier wait, [4] rounds, [5] visits.
+// [0] visit table + slab commit incl. the barrier behind them, [1] visit loop, [2] wait for the next item's facts, [3] wait at
+// the barrier in front of a round (the other waves' last visits + own prefetch issue), [4] rounds, [5] visits.
 __device__ unsigned long long g_wide_prof[8];
 #define GWBP_STAMP(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
 #else
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     for (u32 round = 0;; ++round) { // parity selects the claim counter / visit count in use
     GWBP_STAMP(ts0);
     __syncthreads(); // the previous round's visits are over: slab, table and the other parity's counters are free
+    GWBP_STAMP(tsa);
     const u32 par = round & 1u;
     if (threadIdx.x == 0) {
         ctl[par ^ 1u] = 0, ctl[2u + (par ^ 1u)] = 0; // the next round's counters
@@ -333,7 +335,10 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         }
     }
     const bool stage_plain = !BILINEAR && stage;
-    // (a') the visit table: records with entries in this half, compacted wave by wave (their order does not matter)
+    // (a') the visit table: records with entries in this half, compacted wave by wave, in list order.  (Handing the visits out
+    // longest first -- eight length classes, one more barrier -- was measured: the barrier wait in front of a round fell from
+    // 12 % to 8 % of the wave time, but a visit took 9 % longer (the long, throughput-bound visits then all run together and
+    // so do the short, latency-bound ones), and the pipelined step went from 3.74 to 4.04 ms.  Reverted.)
     {
         const u32 cnt = h1.y;
         const u32 ct = (cnt & 0xFFu) + ((cnt >> 8) & 0xFFu), cb = ((cnt >> 16) & 0xFFu) + (cnt >> 24);
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         wait_info<0>(nx_nrec, nx_toff);
     GWBP_STAMP(ts3);
 #ifdef GWBP_STAMPS
-    prof_acc[0] += ts1 - ts0, prof_acc[1] += ts2 - ts1, prof_acc[2] += ts3 - ts2;
+    prof_acc[0] += ts1 - tsa, prof_acc[1] += ts2 - ts1, prof_acc[2] += ts3 - ts2, prof_acc[3] += tsa - ts0;
     prof_acc[4] += 1ull, prof_acc[5] += (unsigned long long)n_vis_prof;
 #endif
     // ---- the next round, and its loads --------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@ for v in range(V):
     if v >= 1: print("view", v, "scatter ms %.3f" % e0.elapsed_time(e1))
 L.gwbp_profile_read_wide(buf)
 tot = sum(buf[i] for i in range(4))
-names = ["staging+barrier", "visit loop", "drain vmcnt(0)", "end barrier wait"]
+names = ["table+commit+barrier", "visit loop", "next-item wait", "round barrier wait"]
 for i in range(4):
     print("%-18s %5.1f %%" % (names[i], 100.0 * buf[i] / tot))
 print("phases(waves) %d visits %d -> cycles/visit in loop %.0f; per view wave-cycles %.3g" % (buf[4], buf[5], buf[1] / max(1, buf[5]), tot / (V - 1)))
