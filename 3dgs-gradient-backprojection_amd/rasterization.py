@@ -11,6 +11,7 @@ Backward = scatter with v_render_colors as the feature map: colors.grad[g,:] += 
 """
 from __future__ import annotations
 
+import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -19,6 +20,42 @@ from ._lib import GwbpError
 from .engine import TILE, Engine
 
 _ENGINES: Dict[Tuple, Engine] = {}
+# The reference's harvesting pattern hands the SAME all-zero colour table to every view (backproject.py:67-72): whether a
+# table is all zero is found out once per (tensor object, in-place version), not once per call (a 2 GB reduction + a host
+# synchronisation per view at C2).
+_ZERO_TABLES: Dict[int, Tuple] = {}
+# ... and the render of an all-zero table is all zero: one cached [H,W,D] buffer per device and shape instead of a 3.5 GB
+# memset per view.  The buffer is handed out as the operator's output; if anybody wrote into it in place (its version
+# counter moved) it is zeroed again first.
+_ZERO_RENDERS: Dict[Tuple, Tuple] = {}
+
+
+def _is_zero_table(colors: torch.Tensor) -> bool:
+    key = id(colors)
+    hit = _ZERO_TABLES.get(key)
+    if hit is not None and hit[0]() is colors and hit[1] == colors._version:
+        return hit[2]
+    z = not bool(colors.detach().any())
+    if len(_ZERO_TABLES) > 16:
+        _ZERO_TABLES.clear()
+    _ZERO_TABLES[key] = (weakref.ref(colors), colors._version, z)
+    return z
+
+
+def _zero_render(dev, h: int, w: int, d: int) -> torch.Tensor:
+    key = (str(dev), h, w, d)
+    hit = _ZERO_RENDERS.get(key)
+    if hit is not None and hit[0]._version == hit[1]:
+        return hit[0]
+    if hit is not None:
+        hit[0].zero_()
+        buf = hit[0]
+    else:
+        if len(_ZERO_RENDERS) >= 2:  # (the reference alternates between [H,W,512] and [H,W,3])
+            _ZERO_RENDERS.pop(next(iter(_ZERO_RENDERS)))
+        buf = torch.zeros(h, w, d, device=dev, dtype=torch.float32)
+    _ZERO_RENDERS[key] = (buf, buf._version)
+    return buf
 
 
 def get_engine(device, n: int, width: int, height: int) -> Engine:
@@ -91,11 +128,10 @@ class _Rasterize(torch.autograd.Function):
                                             want_store=need_store)
         if D <= 4:  # RGB / RGB+D / depth: pixel-parallel rasteriser straight from the sorted tile lists
             out, alphas = eng.render_pixels(view, colors.detach())
-        elif colors.requires_grad and not bool(colors.detach().any()):
+        elif colors.requires_grad and _is_zero_table(colors):
             # the reference's harvesting pattern: an all-zero differentiable colour table whose render is only there to be
-            # back-propagated through (backproject.py:67-72,115-129) -- the render of zeros is zeros (0.4 ms to find out
-            # instead of a 5.6 ms wide render at C2)
-            out = torch.zeros(view.height, view.width, D, device=dev, dtype=torch.float32)
+            # back-propagated through (backproject.py:67-72,115-129) -- the render of zeros is zeros
+            out = _zero_render(dev, view.height, view.width, D)
         else:
             out = eng.render(view, colors.detach())
         ctx.has_store = need_store
@@ -104,6 +140,8 @@ class _Rasterize(torch.autograd.Function):
         ctx.eng, ctx.view, ctx.gen = eng, view, eng.generation
         ctx.save_for_backward(means, quats, scales, opacities)
         ctx.shape = colors.shape
+        # the leaf whose .grad the backward may add into directly (see backward)
+        ctx.leaf = weakref.ref(colors) if (colors.requires_grad and colors.is_leaf) else None
         ctx.mark_non_differentiable(alphas)
         return out, alphas
 
@@ -120,6 +158,15 @@ class _Rasterize(torch.autograd.Function):
             eng.set_narrow_scatter(ctx.shape[1] % 256 != 0)
             eng.front_cache = None
             _run_front(eng, view, means, quats, scales, opacities, False, False)
+        # The reference keeps ONE grad tensor per colour table alive (it clones and zeroes it in place, backproject.py:130-131),
+        # so a returned gradient would be ADDED to it by autograd: a 2 GB temporary, its memset and a 6 GB read-modify-write
+        # per view at C2.  The scatter kernel accumulates anyway: add straight into the leaf's .grad and hand autograd nothing.
+        leaf = ctx.leaf() if ctx.leaf is not None else None
+        acc = leaf.grad if leaf is not None else None
+        if (acc is not None and acc.dtype == torch.float32 and acc.shape == ctx.shape and acc.is_contiguous()
+                and acc.device == means.device and not torch.is_grad_enabled()):
+            eng.scatter(view, g_out, acc, None)
+            return (None,) * 11
         v_colors = torch.zeros(ctx.shape, device=means.device, dtype=torch.float32)
         eng.scatter(view, g_out, v_colors, None)
         return (v_colors,) + (None,) * 10
@@ -235,4 +282,6 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     meta = LazyMeta(eager, holders, C_) if want_meta else eager
     if want_meta:
         meta._opac = opacities
+    if C_ == 1:  # (no copy of a 3.5 GB render: a view with the camera axis in front)
+        return outs[0][None], alphas[0][None], meta
     return torch.stack(outs), torch.stack(alphas), meta
