@@ -102,6 +102,8 @@ __global__ __launch_bounds__(kScatterThreads) void k_scatter(
     // Software pipeline of depth 1 over records: the next record's header (scalar loads) and its four weight
     // vectors (one coalesced load per quarter) are requested before the current record is processed.
     const Header *hbase = headers + tile_offsets[tile];
+    // a "pixel" whose row lies at or beyond the largest LDS allocation gfx950 has (160 KB), for any pitch: reads as 0
+    const int no_pix = (160 * 1024 / 4 + pitch - 1) / pitch;
     const bool lane_on = 2 * lane < pitch;               // this lane owns channels c0 + 2*lane, +1 (pitch is even)
     const float *lrow = lds + (lane_on ? 2 * lane : 0);  // idle lanes read lane 0's pair and are masked at the flush
 
@@ -151,9 +153,9 @@ __global__ __launch_bounds__(kScatterThreads) void k_scatter(
             const float wv = cur.wv[q]; // lanes >= cnt hold 0
             wacc += wv;
             // (tail lanes [cnt, 64) carry w = 0; they must not read a real pixel -- 0 x NaN / 0 x inf -- so they point
-            // past the slab, where an LDS read returns 0)
+            // beyond any LDS allocation, where a read returns 0)
             const int pl = pixel_list(m, lane, cnt); // (a full permutation: every lane takes part)
-            const int pv = (u32)lane < cnt ? pl : kTilePix + 64; // (+64: clear of the few words behind the slab as well)
+            const int pv = (u32)lane < cnt ? pl : no_pix;
             const float *qrow = lrow + q * 64 * pitch;
             // four pairs per step: independent LDS reads in flight; the tail reads unset pixels with w = 0
             for (u32 k = 0; k < cnt; k += 4) {

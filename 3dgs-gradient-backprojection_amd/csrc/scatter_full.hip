@@ -37,7 +37,7 @@ namespace {
 
 constexpr int kChunk = 128;
 constexpr int kThreads = 1024;
-constexpr u32 kNoPix = 320; // a "pixel" whose slab row lies past the workgroup's LDS allocation: reads as 0
+constexpr u32 kLdsMax = 160u * 1024u; // no LDS allocation on gfx950 is larger: a read at or beyond this byte offset returns 0
 constexpr int kSlabFloats = kTilePix * kChunk; // 32768 floats = 128 KB
 constexpr size_t kLdsBytes = (size_t)kSlabFloats * 4 + 16; // slab + work counter + two item slots
 
@@ -314,6 +314,9 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
     const int chan = lane & ((1 << lgd) - 1);
     const u32 lane_base = SMALL ? (u32)(min(chan, pitch - 1) * sizeof(float)) : (u32)(2 * lane * sizeof(float));
     const u32 row_bytes = (u32)pitch * (u32)sizeof(float);
+    // a "pixel" whose slab row lies at or beyond the largest LDS allocation the hardware has, whatever this launch's pitch
+    // and whatever sits behind the slab (work counter, encoder): zero-weight padding lanes read it (0 x inf at a real pixel is NaN)
+    const u32 kNoPix = (kLdsMax + row_bytes - 1u) / row_bytes;
     const char *slab = reinterpret_cast<const char *>(lds);
     const bool want_d = (chunk == 0) && (dsum_out != nullptr);
 

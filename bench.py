@@ -294,7 +294,9 @@ def main():
         # evidence of what really ran: backend and world size as the process group reports them, every rank's device
         props = torch.cuda.get_device_properties(dev)
         mine = {"rank": rank, "device": f"cuda:{dev.index}", "name": props.name,
-                "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}
+                "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
+                "steps": args.steps}  # views THIS rank timed (strong scaling: ceil / floor of total_views / world; rank 0, whose
+                                      # count "steps" and "ms_per_step" report, always holds the largest share)
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": gathered,

@@ -31,8 +31,8 @@ def main():
     ap.add_argument("--encoder", default=None, help="[512,16] encoder tensor (.pt): backproject_compressed.py")
     ap.add_argument("--synthetic", default=None, help="run a seeded synthetic config (C1, C2, ...) instead of files")
     ap.add_argument("--no-prune", action="store_true",
-                    help="build the field on ALL Gaussians (default, like the reference's main(): prune_by_gradients -> "
-                         "test_proper_pruning -> build on the pruned scene, backproject.py:320-325)")
+                    help="skip the pruning step and build the field on ALL Gaussians (the default, like the reference's main(), "
+                         "is prune_by_gradients -> test_proper_pruning -> build on the pruned scene, backproject.py:320-325)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -78,13 +78,20 @@ def main():
                 f.permute(2, 0, 1)[None], size=(H, W), mode="bilinear")[0].permute(1, 2, 0)
 
     # backproject.py:323-325: splats_optimized = prune_by_gradients(splats); test_proper_pruning(splats, splats_optimized);
-    # the field is then built on the PRUNED scene.  The mask costs one blend per view (no scatter); every rank computes it
-    # over all views (it must be identical everywhere: the accumulators are reduced row by row afterwards).
+    # the field is then built on the PRUNED scene.  The mask costs one blend per view (no scatter).  Under a process group
+    # rank 0 computes it and BROADCASTS it: every rank then slices its Gaussians with the same bits, so the shapes of the
+    # collectives that follow agree by construction (a mask recomputed per rank could differ in a bit -- float atomics -- and
+    # hang the reduce-scatter).
     n_all = means.shape[0]
     keep = None
     if not args.no_prune:
         vm_dev, K_dev = viewmats.to(dev), K.to(dev)
-        keep = gsbp_amd.pruning.gradient_mask(splats, vm_dev, K_dev, W, H)
+        if rank == 0:
+            keep = gsbp_amd.pruning.gradient_mask(splats, vm_dev, K_dev, W, H)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            mask_u8 = keep.to(torch.uint8) if rank == 0 else torch.empty(n_all, dtype=torch.uint8, device=dev)
+            dist.broadcast(mask_u8, src=0)
+            keep = mask_u8.bool()
         if rank == 0:
             print("Total splats", keep.numel())  # utils.py:258-260
             print("Pruned", int((~keep).sum()), "splats")

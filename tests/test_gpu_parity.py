@@ -789,3 +789,40 @@ def test_scatter_encoded_matches_scatter_of_encoded_map(orc, dev, K, n):
                          (feats @ enc).numpy(), Fr, dr)
     assert rel_row_err(res[0][0].cpu().numpy(), Fr) <= TOL
     assert rel_row_err(res[0][1].cpu().numpy()[:, None], dr[:, None]) <= TOL
+
+
+def test_c_abi_refuses_wide_scatter_of_a_narrow_blend_and_leaves_f_and_d_untouched(dev):
+    """include/gwbp.h, gwbp_stats.overflow bit 2: gwbp_scatter asked for the 256-channel kernel (D % 256 == 0, no
+    GWBP_FLAG_NARROW_SCATTER) on a view that was blended WITH the flag finds no weight sums in the headers: the call raises bit 2
+    and leaves BOTH F and d untouched (k_accum_d and the scatter kernel check the same thing), so that the documented recovery
+    -- scatter again with the flag set -- counts nothing twice.  Engine.scatter guards this in Python; here the guard is
+    bypassed and the C ABI is asked directly."""
+    cfg, sc = scene_np("T1")
+    d = to_dev(sc, dev)
+    D = 256
+    eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev)
+    eng.set_narrow_scatter(True)
+    view, _, _ = _front(eng, d, cfg, 0, want=False)
+    eng.blend_weights(view)
+    assert eng.stats()["blend_kind"] == 0
+    feats = syn.make_feature_map(cfg, 0, dim=D).to(dev)
+    F = torch.zeros(cfg.n_gaussians, D, device=dev)
+    dd = torch.zeros(cfg.n_gaussians, device=dev)
+    eng.set_narrow_scatter(False)
+    eng._halves = True  # lie to the Python-side guard: the library must catch it on its own
+    eng.scatter(view, feats, F, dd)
+    st = eng.stats()
+    assert st["overflow"] & 4
+    assert float(F.abs().max()) == 0.0 and float(dd.abs().max()) == 0.0
+    # the documented recovery: the same view through the 128-channel kernel, once
+    eng._halves = False
+    eng.set_narrow_scatter(True)
+    eng.scatter(view, feats, F, dd)
+    F2 = torch.zeros_like(F)
+    d2 = torch.zeros_like(dd)
+    view, _, _ = _front(eng, d, cfg, 0, want=False)
+    eng.blend_weights(view)
+    eng.scatter(view, feats, F2, d2)
+    assert float(dd.sum()) > 0
+    scale = float(F2.norm(dim=1).max())
+    assert float((F - F2).norm(dim=1).max()) <= 2e-5 * scale and float((dd - d2).abs().max()) <= 2e-5 * float(d2.max())

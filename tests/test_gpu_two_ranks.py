@@ -60,6 +60,7 @@ def test_bench_strong_scaling_mode_shards_the_same_views(dev):
     times 3 views; the pair count must equal what one rank counts over the same 7 views."""
     j2 = _bench("--total-views", "7")
     assert j2["scaling"] == "strong" and j2["steps"] == 4 and j2["config"]["total_views"] == 7
+    assert sorted(d["steps"] for d in j2["dist"]["devices"]) == [3, 4]  # what each rank timed
     assert j2["checked"]["ok"] is True and j2["config"]["overflow"] == 0
     import json
     env = dict(os.environ)
@@ -74,3 +75,27 @@ def test_bench_strong_scaling_mode_shards_the_same_views(dev):
     pairs1 = j1["config"]["pairs_per_view"] * 7
     pairs2 = j2["value"] * (j2["ms_per_step"] * 1e-3 * j2["steps"]) / 32  # value = pairs x D / elapsed, D = 32
     assert abs(pairs1 - pairs2) <= 1e-6 * pairs1, (pairs1, pairs2)
+
+
+def test_bench_one_rank_over_rccl(dev):
+    """The exchange step on the REAL backend: `bench.py --gpus 1 --force-dist` initialises an RCCL ("nccl") process group of
+    one rank and runs the reduce-scatter of F and the all-reduce of d through it inside the timed region (strong mode, the 8
+    views of --total-views).  One rank is all a one-GPU box can give RCCL (two ranks on one device are refused); the
+    two-rank bookkeeping is covered over gloo above.  No multi-GPU scaling curve has been measured for this code."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    env["MASTER_PORT"] = str(s.getsockname()[1])
+    s.close()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--total-views", "8",
+                        "--config", "C1", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert j["dist"]["backend"] == "nccl" and j["dist"]["world_size"] == 1
+    assert j["exchange_ms"] > 0 and j["checked"]["ok"] is True
+    assert j["scaling"] == "strong" and j["config"]["total_views"] == 8 and j["steps"] == 8
+    assert [d["steps"] for d in j["dist"]["devices"]] == [8]

@@ -247,3 +247,52 @@ def test_oracle_against_gsplat_capture(orc, fname, cfgname):
         assert rep[k]["p99"] <= 1e-4, (k, rep[k])
         assert rep[k]["rows_over_1e-4"] <= max(1, int(0.002 * rep[k]["rows"])) and rep[k]["max"] <= 1e-2, (k, rep[k])
     assert rep.get("radii", {}).get("visible_equal", True), rep["radii"]
+
+
+def test_capture_script_stays_in_sync_with_its_consumers(orc, gold, tmp_path, monkeypatch):
+    """tools/capture_gsplat_fixture.py cannot run here (it needs CUDA + gsplat 1.4.0); what CAN rot unnoticed is the
+    agreement between the keys it saves and the keys the two consumer tests read (capture_report).  Run its capture()
+    against a stand-in `gsplat` module whose rasterization() is the oracle in the reference's autograd formulation (a dense
+    weight matrix times the differentiable colour table) and feed the file it writes to capture_report: every quantity
+    must be found and -- the stand-in being the oracle -- agree."""
+    import importlib.util
+    import sys
+    import types
+    from util import capture_report
+    g = gold
+
+    def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, **kw):
+        m, q, s, o = (t.detach().numpy() for t in (means, quats, scales, opacities))
+        proj = orc.project(m, q, s, viewmats[0].numpy(), Ks[0].numpy(), width, height)
+        bins = orc.bin_sort(proj, width, height)
+        gid, pix, w, alphas = orc.blend_pairs(proj, bins, o, width, height, want_alphas=True)
+        Wm = torch.zeros(width * height, m.shape[0], dtype=torch.float64)
+        Wm[torch.from_numpy(pix.astype(np.int64)), torch.from_numpy(gid.astype(np.int64))] = torch.from_numpy(w.astype(np.float64))
+        out = (Wm @ colors.double()).to(colors.dtype).reshape(1, height, width, colors.shape[1])
+        meta = {k: torch.from_numpy(np.ascontiguousarray(proj[k]))[None] for k in ("means2d", "radii", "conics", "depths")}
+        meta.update(isect_ids=torch.from_numpy(bins["isect_ids"]), flatten_ids=torch.from_numpy(bins["flatten_ids"]),
+                    tile_size=16, tile_width=-(-width // 16), tile_height=-(-height // 16), width=width, height=height)
+        return out, torch.from_numpy(alphas)[None, ..., None], meta
+
+    stub = types.ModuleType("gsplat")
+    stub.rasterization, stub.__version__ = rasterization, "stand-in (oracle)"
+    monkeypatch.setitem(sys.modules, "gsplat", stub)
+    monkeypatch.setenv("GWBP_CAPTURE_DEVICE", "cpu")
+    spec = importlib.util.spec_from_file_location(
+        "capture_gsplat_fixture", os.path.join(os.path.dirname(os.path.dirname(GOLD)), "..", "tools", "capture_gsplat_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    path = str(tmp_path / "gsplat_g0.npz")
+    mod.capture({k: g[k] for k in ("means", "quats", "scales", "opac", "K", "vms", "feats")}, path)
+    cap = dict(np.load(path))
+    out, F, d, _ = orc.backproject_oracle(g["means"], g["quats"], g["scales"], g["opac"], g["vms"], g["K"], W0, H0,
+                                          lambda v: g["feats"][v], 8)
+    proj = orc.project(g["means"], g["quats"], g["scales"], g["vms"][0], g["K"], W0, H0)
+    rep = capture_report(cap, out, F, d, proj["radii"], proj["means2d"], proj["conics"], proj["depths"])
+    for k in ("F", "d", "out"):
+        assert rep[k]["rows"] == 256 and rep[k]["max"] <= 1e-5, (k, rep[k])
+    assert rep["radii"] == {"visible_equal": True, "n_diff": 0}
+    for k in ("means2d", "conics", "depths"):
+        assert rep[k]["max_rel"] == 0.0, (k, rep[k])
+    for k in ("v0_alphas", "v0_isect_ids", "v0_flatten_ids", "F_views", "d_views", "gsplat_version"):
+        assert k in cap, k

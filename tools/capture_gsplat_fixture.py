@@ -33,7 +33,9 @@ def capture(inp, out_path):
     import torch
     from gsplat import rasterization  # the reference's import (backproject.py:7)
     import gsplat
-    dev = torch.device("cuda")
+    # (GWBP_CAPTURE_DEVICE=cpu exists for tests/test_oracle.py::test_capture_script_stays_in_sync_with_its_consumers, which runs
+    # this function against a stand-in `gsplat` module; a real capture runs on CUDA)
+    dev = torch.device(os.environ.get("GWBP_CAPTURE_DEVICE", "cuda"))
     t = {k: torch.from_numpy(np.asarray(inp[k])).to(dev) for k in ("means", "quats", "scales", "opac", "K", "vms", "feats")}
     N, (V, H, W, D) = t["means"].shape[0], t["feats"].shape
     F = torch.zeros(N, D, device=dev)
@@ -64,7 +66,7 @@ def capture(inp, out_path):
         return None if val is None else val.detach().cpu().numpy()
 
     save = dict(gsplat_version=np.array(gsplat.__version__), torch_version=np.array(torch.__version__),
-                device=np.array(torch.cuda.get_device_name(0)),
+                device=np.array(torch.cuda.get_device_name(0) if dev.type == "cuda" else str(dev)),
                 F=F.cpu().numpy(), d=d.cpu().numpy(), out=x.cpu().numpy(),
                 F_views=torch.stack(Fv).cpu().numpy(), d_views=torch.stack(dv).cpu().numpy(),
                 v0_alphas=alphas0[0, ..., 0].detach().cpu().numpy())
