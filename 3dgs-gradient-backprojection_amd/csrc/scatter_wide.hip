@@ -58,7 +58,10 @@ constexpr int kWide = 256;             // channels per chunk
 constexpr int kHalfPix = kTilePix / 2; // pixels per slab
 constexpr int kThreads = 1024;
 constexpr int kSlabFloats = kHalfPix * kWide; // 32768 floats = 128 KB
-constexpr int kVisCap = kThreads;             // records per round = visit-table capacity (one record per thread)
+#ifndef GWBP_VISCAP
+#define GWBP_VISCAP 1024
+#endif
+constexpr int kVisCap = GWBP_VISCAP;          // records per round = visit-table capacity (threads 0 .. kVisCap-1 take one record each)
 constexpr u32 kTabOff = (u32)kSlabFloats * 4u;         // visit table: kVisCap x 16 B behind the slab
 constexpr u32 kCtlOff = kTabOff + (u32)kVisCap * 16u;  // control words: [0,1] claim counters and [2,3] visit counts by round
                                                        // parity, [4,5] item slots
@@ -121,12 +124,19 @@ struct Land { // what a visit prefetches: two entry vectors and the four carry d
 };
 // All VMEM of the visit loop: address = SGPR pair + per-lane 32-bit offset + immediate.  Tied operands ("+v"): the load
 // must land in the registers the struct lives in (scatter_full.hip explains what happens otherwise).
+// `lanes` = the lanes that hold an entry of the visit: the others issue no request (they would fetch the next records' entries:
+// 1 KB per visit whatever its length, +1.1 GB of fabric reads per C2 view) and keep their old register contents, which the
+// selects that consume the landing buffer mask out anyway.  The instruction is issued either way: the counted waits stand.
 template <int OFF>
-__device__ __forceinline__ void load_e(EV &dst, u32 voff, u64 base)
+__device__ __forceinline__ void load_e(EV &dst, u32 voff, u64 base, u64 lanes)
 {
-    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3"
-                 : "+v"(*reinterpret_cast<float2 *>(&dst))
-                 : "v"(voff), "s"(base), "n"(OFF)
+    u64 saved;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, %5\n\t"
+                 "global_load_dwordx2 %0, %2, %3 offset:%4\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "+v"(*reinterpret_cast<float2 *>(&dst)), "=&s"(saved)
+                 : "v"(voff), "s"(base), "n"(OFF), "s"(lanes)
                  : "memory");
 }
 // sc1: served by L2, never by this CU's L1 (the row was written by another wave of this workgroup one pass earlier)
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         // (a) this round's records
         const u32 rec = rbase + threadIdx.x;
         h0 = make_uint4(0u, 0u, 0u, 0u), h1 = make_uint2(0u, 0u);
-        if (rec < n_rec) {
+        if (threadIdx.x < (u32)kVisCap && rec < n_rec) {
             h0 = *reinterpret_cast<const uint4 *>(hbase + rec);   // gid, woff[0..2]
             h1 = reinterpret_cast<const uint2 *>(hbase + rec)[2]; // woff[3], counts
         }
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
             ctl[4 + ((k + 1u) & 1u)] = next_claim; // (claimed a round ago: its round trip is over)
     }
     const u32 rec = rbase + threadIdx.x;
-    const bool has = rec < n_rec;
+    const bool has = threadIdx.x < (u32)kVisCap && rec < n_rec;
     const bool stage = !(kAbl & 4) && n_rec != 0 && rbase == 0;
     if (BILINEAR && stage) {
         // Bilinear low-resolution map (backproject.py:110-112 folded in): every slab value is the blend of four texels
@@ -396,8 +406,9 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     // exactly 2 (top pass) / 6 (bottom pass) VMEM loads: the top pass never resumes a record
     auto prefetch = [&](const Visit &R, Land &x, auto bottom) __attribute__((always_inline)) {
         const u64 eb = sbase(reinterpret_cast<u64>(wpool) + ((u64)R.off << 3));
-        load_e<0>(x.e[0], lane8, eb); // lanes >= n read past the visit's entries (the pool has 1 KB of slack): masked below
-        load_e<512>(x.e[1], lane8, eb);
+        const u32 n0 = min(R.n, 64u), n1 = R.n - n0;
+        load_e<0>(x.e[0], lane8, eb, n0 == 64u ? ~0ull : (1ull << n0) - 1ull);
+        load_e<512>(x.e[1], lane8, eb, n1 == 64u ? ~0ull : (1ull << n1) - 1ull);
         if constexpr (decltype(bottom)::value) {
             // carry dwords of this lane (non-spanning records: row 0, value ignored -- the count must stay exact)
             const u64 cr = sbase(carry + ((u64)((R.span && !(kAbl & 16)) ? R.row : 0u) << 10));
