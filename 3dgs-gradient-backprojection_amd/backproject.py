@@ -131,7 +131,7 @@ class ViewPipeline:
 
     def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None,
                  allow_wide: bool = True, scatter_workgroups: Optional[int] = None, side_priority: int = -1,
-                 front_priority: Optional[bool] = None, fuse_small: bool = True):
+                 front_priority: Optional[bool] = None, fuse_small: bool = True, side_streams: Optional[int] = None):
         self.dev = torch.device(device)
         self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev, tight_binning=True)
                                                   for _ in range(2)]
@@ -163,6 +163,8 @@ class ViewPipeline:
         # atomics anyway.  (With separate blend and scatter kernels this schedule was measured to change nothing.)
         self.independent = K > 2 and self.fuse_small
         n_side = K if self.independent else max(1, K - 1)
+        if side_streams is not None and not self.independent:
+            n_side = max(1, min(int(side_streams), K - 1))
         self.sides = [torch.cuda.Stream(device=self.dev, priority=int(side_priority)) for _ in range(n_side)]
         self.side = self.sides[0]
         self.enc_stream = None  # encoder stream, created by the first encode_ahead()

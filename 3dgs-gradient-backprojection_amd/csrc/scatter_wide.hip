@@ -66,6 +66,20 @@ constexpr u32 kTabOff = (u32)kSlabFloats * 4u;         // visit table: kVisCap x
 constexpr u32 kCtlOff = kTabOff + (u32)kVisCap * 16u;  // control words: [0,1] claim counters and [2,3] visit counts by round
                                                        // parity, [4,5] item slots
 constexpr size_t kLdsBytes = kCtlOff + 32;
+#ifndef GWBP_TAIL
+#define GWBP_TAIL 0
+#endif
+constexpr int kTail = GWBP_TAIL; // visits held back for the end of a round (0 = the table is in list order).  Measured with 16 / 32 /
+                                 // 48 / 96: the kernel beside the front stage 6-8 % faster (the waves run out of work together), the
+                                 // front stage beside it 10 % slower, the step 3.62 -> 3.96 ms: off, like GWBP_HALFBATCH below
+constexpr int kShortN = 16;      // ... chosen among the visits of at most this many entries
+#ifndef GWBP_HALFBATCH
+#define GWBP_HALFBATCH 0
+#endif
+constexpr bool kHalfBatch = GWBP_HALFBATCH != 0;
+#ifndef GWBP_BATCH_LOOP
+#define GWBP_BATCH_LOOP 0
+#endif
 constexpr u32 kNoPix = 640; // a "pixel" whose slab row lies beyond the 160 KB an LDS allocation can have: reads as 0
 
 // Structure-preserving ablations (make PROFILE=1 ABL=<bits> via tools/build_ablations.sh; results INVALID by design, never in
@@ -197,12 +211,11 @@ __device__ __forceinline__ void wait_lds(u32x4_t &a) { asm volatile("s_waitcnt l
 // vector registers.
 __device__ __forceinline__ u64 sbase(u64 x)
 {
-    if (!(kAbl & 2))
-        return x;
+    // hipcc does not always prove these bases wave-uniform (it depends on the shape of the surrounding loops), and a vector
+    // register in an "s" operand is a compile error at best: force the issue.  v_readfirstlane -> VMEM address operand needs 5
+    // wait states and the hazard recogniser does not look inside inline asm, hence the s_nop (tools/check_asm_hazards.py and
+    // a CPU test scan the generated code for the pattern).
     x = uniform64(x);
-    // v_readfirstlane -> VMEM address operand needs 5 wait states, and the hazard recogniser does not look inside inline asm
-    // (the first no-compute build faulted on exactly that).  The product build forms its bases on the scalar ALU:
-    // tests/test_capi_cpu.py scans the generated code for the pattern.
     asm volatile("s_nop 4" : "+s"(x));
     return x;
 }
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     const u64 carry = reinterpret_cast<u64>(carry_all + (size_t)blockIdx.x * kCarryRows * kWide); // this workgroup's slice
     const float *feats = M.p;
     if (threadIdx.x == 0) {
-        ctl[0] = ctl[1] = ctl[2] = ctl[3] = 0;
+        ctl[0] = ctl[1] = ctl[2] = ctl[3] = ctl[6] = ctl[7] = 0;
         ctl[4] = atomicAdd(queue, 1u);
     }
     __syncthreads();
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     GWBP_STAMP(tsa);
     const u32 par = round & 1u;
     if (threadIdx.x == 0) {
-        ctl[par ^ 1u] = 0, ctl[2u + (par ^ 1u)] = 0; // the next round's counters
+        ctl[par ^ 1u] = 0, ctl[2u + (par ^ 1u)] = 0, ctl[6u + (par ^ 1u)] = 0; // the next round's counters
         if (phase == 0 && rbase == 0)
             ctl[4 + ((k + 1u) & 1u)] = next_claim; // (claimed a round ago: its round trip is over)
     }
@@ -357,12 +370,37 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         const bool valid = has && n != 0;
         const u64 m = __ballot(valid);
         if (m != 0ull) { // wave-uniform
-            u32 wbase = 0;
-            if (lane == 0)
-                wbase = atomicAdd(&ctl[2u + par], (u32)__popcll(m));
-            wbase = uniform(wbase);
-            if (valid)
-                table[wbase + mbcnt(m)] = make_uint4(h0.x, phase ? h0.w : h0.y, n | span, rec);
+            // kTail > 0: the first kTail SHORT visits (<= kShortN entries) are parked at the END of the table, i.e. handed out
+            // last -- the waves then run out of work within one short visit of each other (ctl[2 + par] counts the front part,
+            // ctl[6 + par] the candidates for the tail)
+            u64 mback = 0ull;
+            if (kTail > 0) {
+                const u64 ms = __ballot(valid && n <= (u32)kShortN);
+                if (ms != 0ull) {
+                    u32 sbase_ = 0;
+                    if (lane == 0)
+                        sbase_ = atomicAdd(&ctl[6u + par], (u32)__popcll(ms));
+                    sbase_ = uniform(sbase_);
+                    // (signed on purpose: written as `kTail > sbase_ ? min(kTail - sbase_, ..) : 0` in unsigned arithmetic, hipcc 7.2
+                    // emitted s_sub_i32 + s_min_u32 without the saturation -- waves that arrived after the tail was full parked
+                    // ALL their short visits beyond its end, where nobody claims them)
+                    const int room = max(kTail - (int)sbase_, 0);
+                    const u32 take = (u32)min(room, (int)__popcll(ms));
+                    const bool back = valid && n <= (u32)kShortN && mbcnt(ms) < take;
+                    mback = __ballot(back);
+                    if (back)
+                        table[(u32)kVisCap - 1u - (sbase_ + mbcnt(ms))] = make_uint4(h0.x, phase ? h0.w : h0.y, n | span, rec);
+                }
+            }
+            const u64 mf = m & ~mback;
+            if (mf != 0ull) {
+                u32 wbase = 0;
+                if (lane == 0)
+                    wbase = atomicAdd(&ctl[2u + par], (u32)__popcll(mf));
+                wbase = uniform(wbase);
+                if ((mf >> lane) & 1ull)
+                    table[wbase + mbcnt(mf)] = make_uint4(h0.x, phase ? h0.w : h0.y, n | span, rec);
+            }
         }
     }
     if (stage_plain) {
@@ -375,7 +413,12 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
 #ifdef GWBP_STAMPS
     u32 n_vis_prof = 0;
 #endif
-    const u32 nv = uniform(ctl[2u + par]);
+    const u32 n_front = uniform(ctl[2u + par]);
+    const u32 nv = n_front + (kTail > 0 ? min(uniform(ctl[6u + par]), (u32)kTail) : 0u);
+    // claim index -> table slot (the held-back visits sit at the end of the table, last slot first)
+    auto slot_of = [&](u32 h) __attribute__((always_inline)) -> u32 {
+        return (kTail > 0 && h >= n_front) ? (u32)kVisCap - 1u - (h - n_front) : h;
+    };
     const u32 claim_addr = kCtlOff + 4u * par;
     const u64 f_base = uniform64(f_chunk); // (a loop-carried value: hipcc does not prove it scalar, and an "s" operand must be)
     // The next item's tile facts (record count, first header), fetched under this pass's visits: two loads of the asm-counted
@@ -432,35 +475,64 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         // The batch is scheduled by hand (sched_barrier): all eight pixel indices are read into scalar registers BEFORE the
         // first address is formed and all eight weights before the first FMA -- left alone, hipcc chains readlane -> address ->
         // read through ONE scalar register and pays a hazard s_nop per pair (twice: addresses and FMAs).
-#define GWBP_ISSUE(B)                                                                                                 \
-    u32 px_[kB];                                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < kB; ++j) px_[j] = readlane_u(ev.pix, kB * (B) + j);                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                                \
-    _Pragma("unroll") for (int j = 0; j < kB; ++j) f[j] = lds_read_b128((px_[j] << 10) + row_base);                   \
-    __builtin_amdgcn_sched_barrier(0);
-#define GWBP_FMA(B)                                                                                                   \
-    float w_[kB];                                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < kB; ++j) w_[j] = readlane_f(ev.w, kB * (B) + j);                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                                \
-    _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                    \
+        // KB = 8: a full batch.  Two build options that were measured and are OFF:
+        //   GWBP_HALFBATCH=1   a vector whose last batch holds 1..4 entries ends with a HALF batch (KB = 4) instead of a batch
+        //                      padded to eight pairs with zero weights.  It removes ~1 % of the kernel's vector instructions (C2's
+        //                      remainders are mostly 5..8) and makes the kernel 6 % faster beside the front stage -- and the front
+        //                      stage 12 % slower beside it (k_radix_scatter 0.15 -> 0.55 ms per pass, k_project 0.1 -> 1.1 ms
+        //                      under overlap; wave priority, free CUs, the blend's workgroup shape and the visit table's LDS share
+        //                      were all ruled out as the cause): the step went from 3.62 to 4.0 ms.
+        //   GWBP_BATCH_LOOP=1  the batches as a run-time loop (v_readlane with the lane index in a scalar register): 12 KB of code
+        //                      instead of 20-28, built to test whether code size was what hurt the front; it was not, and the
+        //                      kernel alone went from 3.2 to 3.6 ms.
+#define GWBP_BATCH(B0, KB)                                                                                            \
     {                                                                                                                 \
-        acc_lo = pk_fma(w_[j], f[j].xy, acc_lo);                                                                      \
-        acc_hi = pk_fma(w_[j], f[j].zw, acc_hi);                                                                      \
-    }                                                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);
+        u32 px_[KB];                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < KB; ++j) px_[j] = readlane_u(ev.pix, (int)((B0) + j));                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        _Pragma("unroll") for (int j = 0; j < KB; ++j) f[j] = lds_read_b128((px_[j] << 10) + row_base);               \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        float w_[KB];                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < KB; ++j) w_[j] = readlane_f(ev.w, (int)((B0) + j));                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        _Pragma("unroll") for (int j = 0; j < KB; ++j)                                                                \
+        {                                                                                                             \
+            acc_lo = pk_fma(w_[j], f[j].xy, acc_lo);                                                                  \
+            acc_hi = pk_fma(w_[j], f[j].zw, acc_hi);                                                                  \
+        }                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }
+#if GWBP_BATCH_LOOP
+        // first batch (always there: n >= 1), then the claim's descriptor read, then the rest
+        if (kHalfBatch && n <= 4u) {
+            GWBP_BATCH(0u, 4)
+        } else {
+            GWBP_BATCH(0u, 8)
+        }
+        after_first();
+#pragma unroll 1
+        for (u32 b0 = (u32)kB; b0 < n; b0 += (u32)kB) {
+            if (kHalfBatch && n - b0 <= 4u) {
+                GWBP_BATCH(b0, 4)
+            } else {
+                GWBP_BATCH(b0, 8)
+            }
+        }
+#else
 #pragma unroll
         for (int B = 0; B < 64 / kB; ++B) {
             if ((u32)kB * B >= n)
                 break;
-            {
-                GWBP_ISSUE(B)
-                GWBP_FMA(B)
+            if (kHalfBatch && n - (u32)kB * B <= 4u) {
+                GWBP_BATCH(kB * B, 4)
+            } else {
+                GWBP_BATCH(kB * B, 8)
             }
             if (B == 0)
                 after_first();
         }
-#undef GWBP_ISSUE
-#undef GWBP_FMA
+#endif
+#undef GWBP_BATCH
     };
 
     // Visit pipeline.  `cur` is processed, the entries of `nxt` are in flight into the landing buffer (loaded at the top of
@@ -475,11 +547,11 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         const u32 h_cur = uniform(cl);
         if (h_cur < nv) {
             claim_issue(cl, claim_addr, lane);
-            Visit cur = decode(table[h_cur]);
+            Visit cur = decode(table[slot_of(h_cur)]);
             prefetch(cur, L, bottom);
             wait_lds(cl);
             u32 h_nxt = uniform(cl);
-            Visit nxt = decode(table[min(h_nxt, nv - 1u)]);
+            Visit nxt = decode(table[slot_of(min(h_nxt, nv - 1u))]);
             wait_land<0>(L); // (one exposed L2 round trip per wave and pass; the steady-state wait below then holds from the start)
             for (;;) {
                 const bool vnxt = h_nxt < nv;
@@ -514,7 +586,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
                     // the claim has returned with the first batch (LDS operations complete in order): read its descriptor
                     wait_lds(cl);
                     h_n2 = uniform(cl);
-                    table_issue(tn, kTabOff + 16u * min(h_n2, nv - 1u));
+                    table_issue(tn, kTabOff + 16u * slot_of(min(h_n2, nv - 1u)));
                     have_n2 = true;
                 };
                 if (!(kAbl & 2)) {

@@ -51,6 +51,9 @@ def main():
                     help="every rank uses cuda:0 (checks the N > 1 bookkeeping on a one-GPU box together with --dist-backend gloo)")
     ap.add_argument("--depth", type=int, default=0,
                     help="workspaces / views in flight of the pipeline (0 = auto: 4 for small scenes, 2 for narrow maps on large ones, else 3)")
+    ap.add_argument("--side-streams", type=int, default=None,
+                    help="streams the front stages are spread over (default: one per workspace beyond the first; 1 = the fronts "
+                         "of consecutive views run one after the other on ONE stream, up to depth - 1 views ahead)")
     ap.add_argument("--enc-wgs-per-cu", type=float, default=None, help="C5 tuning: encoder workgroups per CU in the pipeline")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run result check (the `checked` object)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
@@ -147,7 +150,7 @@ def main():
         pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng] + more, scatter_dim=D, allow_wide=allow_wide,
                                      scatter_workgroups=args.pipe_wgs, side_priority=args.side_prio,
                                      front_priority=None if args.front_prio == "auto" else args.front_prio == "on",
-                                     fuse_small=not args.no_fuse_small)
+                                     fuse_small=not args.no_fuse_small, side_streams=args.side_streams)
         accum = pipe.accum
         if args.enc_wgs_per_cu:
             pipe.ENCODER_WORKGROUPS_PER_CU = args.enc_wgs_per_cu

@@ -1,6 +1,7 @@
 #!/bin/bash
 # On the GPU box: pipeline knobs of bench.py (workspaces in flight, wave priority of the front kernels, stream priority).
-for args in "--depth 3" "--depth 4" "--depth 3 --front-prio off" "--depth 4 --front-prio off" "--depth 3 --side-prio 0" "--depth 3 --front-prio off --side-prio 0" "--depth 3 --pipe-wgs 248" "${EXTRA:-}"; do
+# usage: [GWBP_LIB=...] tools/sweep_knobs.sh "<args 1>" "<args 2>" ...
+for args in "$@"; do
   python bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-check $args > /tmp/b.json 2>/dev/null
   python - "$args" <<'PY'
 import json,sys
