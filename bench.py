@@ -51,6 +51,7 @@ def main():
                     help="every rank uses cuda:0 (checks the N > 1 bookkeeping on a one-GPU box together with --dist-backend gloo)")
     ap.add_argument("--depth", type=int, default=0,
                     help="workspaces / views in flight of the pipeline (0 = auto: 4 for small scenes, 2 for narrow maps on large ones, else 3)")
+    ap.add_argument("--isect-cap", type=int, default=None, help="intersection capacity of the workspaces (tuning; default 16 N)")
     ap.add_argument("--side-streams", type=int, default=None,
                     help="streams the front stages are spread over (default: one per workspace beyond the first; 1 = the fronts "
                          "of consecutive views run one after the other on ONE stream, up to depth - 1 views ahead)")
@@ -127,7 +128,7 @@ def main():
     # feature-map pool, generated on device (seeded), L2-normalised over channels like backproject.py:109
     pool = [syn.make_feature_map(cfg, 1000 * rank + i, device=dev) for i in range(args.pool)]
     tight = not args.exact_binning
-    eng = gsbp_amd.Engine(N, W, H, device=dev, tight_binning=tight)
+    eng = gsbp_amd.Engine(N, W, H, device=dev, tight_binning=tight, isect_cap=args.isect_cap)
     F, d, F_store = gsbp_amd.backproject.alloc_accumulators(N, D, dev, world)
     views = [eng.view(vms[v], K, W, H) for v in my_views]
 
