@@ -198,13 +198,14 @@ __device__ __forceinline__ void claim_issue(u32 &dst, u32 addr, int lane)
         asm volatile("ds_add_rtn_u32 %0, %1, %2" : "+v"(dst) : "v"(addr), "v"(one) : "memory");
     }
 }
-typedef u32 u32x4_t __attribute__((ext_vector_type(4))); // a native vector: HIP's uint4 is a struct, not an asm operand
-__device__ __forceinline__ void table_issue(u32x4_t &dst, u32 addr)
+typedef u32 u32x3_t __attribute__((ext_vector_type(3))); // a native vector: HIP's uint3 is a struct, not an asm operand
+// (12 of a table entry's 16 bytes: three registers in flight per wave instead of four -- see the note on lane8 below)
+__device__ __forceinline__ void table_issue(u32x3_t &dst, u32 addr)
 {
-    asm volatile("ds_read_b128 %0, %1" : "+v"(dst) : "v"(addr) : "memory");
+    asm volatile("ds_read_b96 %0, %1" : "+v"(dst) : "v"(addr) : "memory");
 }
 __device__ __forceinline__ void wait_lds(u32 &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
-__device__ __forceinline__ void wait_lds(u32x4_t &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
+__device__ __forceinline__ void wait_lds(u32x3_t &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
 
 // An "s" asm operand must really be scalar: hipcc does not insert the v_readfirstlane itself.  In the product build every base
 // below is provably wave-uniform (a compile error otherwise, never a silent miscompile); the no-compute ablation keeps them in
@@ -235,6 +236,13 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
             atomicOr(&ctr->overflow, kOverflowMismatch);
         return;
     }
+    // REGISTER BUDGET, deliberately padded.  The kernel needs 75 vector registers; naming v103 makes the hardware allocate 104
+    // per lane to each of its four waves per SIMD, which leaves 96: ONE 64-register wave of the front-stage kernels (k_blend,
+    // k_radix_scatter) per SIMD beside it.  Measured on one box (C2, three workspaces), allocation -> ms per view:
+    // 80 (three front waves per SIMD) 3.74, 88 / 96 (two) 3.72, 104 (one) 3.64, 112 (one) 3.67, 120 (none: the front's
+    // kernels wait for the scatter kernel to END) 3.97.  More front waves beside the kernel cost it more than they gain.
+    // tests/test_capi_cpu.py pins the allocation.
+    asm volatile("" ::: "v103");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     u32 *ctl = reinterpret_cast<u32 *>(lds) + kCtlOff / 4;
     uint4 *table = reinterpret_cast<uint4 *>(lds) + kTabOff / 16;
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     const u32 n_items = (u32)((n_tiles - (int)xcls + 7) / 8) * (u32)n_chunks;
     u32 *queue = queues + xcls * 16;
     const int lane = threadIdx.x & 63;
-    const u32 lane4 = (u32)lane * 4u, lane8 = (u32)lane * 8u;
+    const u32 lane4 = (u32)lane * 4u;
     const u64 carry = reinterpret_cast<u64>(carry_all + (size_t)blockIdx.x * kCarryRows * kWide); // this workgroup's slice
     const float *feats = M.p;
     if (threadIdx.x == 0) {
@@ -282,7 +290,13 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     uint4 h0 = make_uint4(0u, 0u, 0u, 0u);
     uint2 h1 = make_uint2(0u, 0u);
     constexpr int kUnits = kHalfPix / (kThreads / 64); // 8 pixels per wave
-    float4 vals[kUnits];
+    // ONE 32-register buffer serves as the landing area of the next slab's loads (from the end of a round to the commit at the
+    // top of the next) AND as the batch buffer of the visit loop in between: declared separately, hipcc gave them 32 registers
+    // each (110 VGPRs -> 112 allocated, ONE 64-register front-stage wave per SIMD beside the kernel; 113+ -> 120: none at all,
+    // and k_project / k_radix_scatter of the next views then waited for the scatter kernel to END -- which is what four
+    // 'improvements' of the kernel ran into this round).
+    static_assert(kUnits == 8, "the slab landing area and the batch buffer are the same eight float4");
+    f32x4_t fbuf[kUnits];
     u32 next_claim = 0; // thread 0: the item after this one, claimed when this one was started
     const int wv = (int)uniform(threadIdx.x >> 6);
     auto stage_issue = [&]() __attribute__((always_inline)) {
@@ -309,8 +323,15 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
 #pragma unroll
             for (int u = 0; u < kUnits; ++u) {
                 const float *src = rows[u] + lane;
-                vals[u] = make_float4(src[0], src[64], src[128], src[192]);
+                fbuf[u] = f32x4_t{src[0], src[64], src[128], src[192]};
             }
+        } else {
+            // No slab for the next round: say so.  Without this the buffer's OLD contents count as live from one round's end to
+            // the next (a conditional redefinition), i.e. right through the visit loop, and its 32 registers cannot double
+            // as the loop's batch buffer.
+#pragma unroll
+            for (int u = 0; u < kUnits; ++u)
+                asm volatile("" : "=v"(fbuf[u]));
         }
     };
     if (item < n_items) {
@@ -318,12 +339,16 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     if (threadIdx.x == 0)
         next_claim = atomicAdd(queue, 1u);
     stage_issue();
-#pragma unroll 1
-    for (u32 round = 0;; ++round) { // parity selects the claim counter / visit count in use
+    // The top of a round -- wait for the previous round's visits, build the visit table, commit the slab -- is issued right
+    // BEHIND the loads it consumes (end of the previous round), inside the same loop iteration: with the loads at the end of one
+    // iteration and their consumers at the top of the next, the 32 slab registers are loop-carried values that hipcc will not
+    // let share registers with the visit loop's batch buffer.
+    u32 round = 0, par = 0; // parity selects the claim counter / visit count in use
+    auto setup_round = [&]() __attribute__((always_inline)) {
     GWBP_STAMP(ts0);
     __syncthreads(); // the previous round's visits are over: slab, table and the other parity's counters are free
     GWBP_STAMP(tsa);
-    const u32 par = round & 1u;
+    par = round & 1u;
     if (threadIdx.x == 0) {
         ctl[par ^ 1u] = 0, ctl[2u + (par ^ 1u)] = 0, ctl[6u + (par ^ 1u)] = 0; // the next round's counters
         if (phase == 0 && rbase == 0)
@@ -389,7 +414,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
                     const bool back = valid && n <= (u32)kShortN && mbcnt(ms) < take;
                     mback = __ballot(back);
                     if (back)
-                        table[(u32)kVisCap - 1u - (sbase_ + mbcnt(ms))] = make_uint4(h0.x, phase ? h0.w : h0.y, n | span, rec);
+                        table[(u32)kVisCap - 1u - (sbase_ + mbcnt(ms))] = make_uint4(h0.x, phase ? h0.w : h0.y, n | span | (rec << 16), 0u);
                 }
             }
             const u64 mf = m & ~mback;
@@ -399,16 +424,26 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
                     wbase = atomicAdd(&ctl[2u + par], (u32)__popcll(mf));
                 wbase = uniform(wbase);
                 if ((mf >> lane) & 1ull)
-                    table[wbase + mbcnt(mf)] = make_uint4(h0.x, phase ? h0.w : h0.y, n | span, rec);
+                    table[wbase + mbcnt(mf)] = make_uint4(h0.x, phase ? h0.w : h0.y, n | span | (rec << 16), 0u);
             }
         }
     }
     if (stage_plain) {
 #pragma unroll
         for (int u = 0; u < kUnits; ++u) // slab row = pixel (tile row u of this half, column wv)
-            *reinterpret_cast<float4 *>(lds + (u * kTile + wv) * kWide + 4 * lane) = vals[u];
+            *reinterpret_cast<f32x4_t *>(lds + (u * kTile + wv) * kWide + 4 * lane) = fbuf[u];
     }
     __syncthreads();
+#ifdef GWBP_STAMPS
+    {
+        GWBP_STAMP(tsb);
+        prof_acc[3] += tsa - ts0, prof_acc[0] += tsb - tsa;
+    }
+#endif
+    };
+    setup_round();
+#pragma unroll 1
+    for (;;) {
     GWBP_STAMP(ts1);
 #ifdef GWBP_STAMPS
     u32 n_vis_prof = 0;
@@ -440,16 +475,22 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         Visit r;
         r.gid = uniform(t.x);
         r.off = uniform(t.y);
-        const u32 ns = uniform(t.z);
+        const u32 ns = uniform(t.z); // entries | spans both halves << 8 | record index (= carry row) << 16
         r.n = ns & 0xFFu;
         r.span = ns & 0x100u;
-        r.row = uniform(t.w);
+        r.row = ns >> 16;
         return r;
     };
     // exactly 2 (top pass) / 6 (bottom pass) VMEM loads: the top pass never resumes a record
     auto prefetch = [&](const Visit &R, Land &x, auto bottom) __attribute__((always_inline)) {
         const u64 eb = sbase(reinterpret_cast<u64>(wpool) + ((u64)R.off << 3));
         const u32 n0 = min(R.n, 64u), n1 = R.n - n0;
+        // lane * 8, formed here and not kept: ONE register decides whether the kernel is allocated 80 or 88 VGPRs per lane
+        // (next_free_vgpr <= 79 / >= 80), i.e. whether three or two 64-register front-stage waves fit on a SIMD beside the four
+        // scatter waves -- at 88 the front stage beside the kernel runs 10 % slower and the step goes from 3.65 to 3.97 ms
+        // (the asm keeps hipcc from hoisting the shift out of the visit loop)
+        u32 lane8;
+        asm volatile("v_lshlrev_b32 %0, 1, %1" : "=v"(lane8) : "v"(lane4));
         load_e<0>(x.e[0], lane8, eb, n0 == 64u ? ~0ull : (1ull << n0) - 1ull);
         load_e<512>(x.e[1], lane8, eb, n1 == 64u ? ~0ull : (1ull << n1) - 1ull);
         if constexpr (decltype(bottom)::value) {
@@ -468,7 +509,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         // ONE batch of 8 float4 in flight (32 VGPRs): the other waves of the SIMD cover the LDS latency between the
         // eight reads and the first FMA.
         constexpr int kB = 8;
-        f32x4_t f[kB];
+        f32x4_t(&f)[kB] = fbuf;
         // LDS address = slab row of the pixel + this lane's 16 B: ONE v_lshl_add_u32 per pair straight from the
         // v_readlane'd pixel index (row_base already carries -128 rows in the bottom pass, where every real entry has
         // pix >= 128; masked lanes point at kNoPix, far beyond any LDS allocation -- an out-of-range LDS read returns 0).
@@ -541,7 +582,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     auto visits = [&](auto bottom) __attribute__((always_inline)) -> bool {
         Land L = {{{0.f, 0u}, {0.f, 0u}}, {0.f, 0.f, 0.f, 0.f}};
         u32 cl = 0;
-        u32x4_t tn = {0u, 0u, 0u, 0u};
+        u32x3_t tn = {0u, 0u, 0u};
         claim_issue(cl, claim_addr, lane);
         wait_lds(cl);
         const u32 h_cur = uniform(cl);
@@ -624,7 +665,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
                 if (!vnxt)
                     break;
                 cur = nxt;
-                nxt = decode(make_uint4(tn.x, tn.y, tn.z, tn.w));
+                nxt = decode(make_uint4(tn.x, tn.y, tn.z, 0u));
                 h_nxt = h_n2;
             }
             wait_land<kFlush>(L); // the last prefetch still targets the landing registers (the last flush may stay in flight)
@@ -647,7 +688,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         wait_info<0>(nx_nrec, nx_toff);
     GWBP_STAMP(ts3);
 #ifdef GWBP_STAMPS
-    prof_acc[0] += ts1 - tsa, prof_acc[1] += ts2 - ts1, prof_acc[2] += ts3 - ts2, prof_acc[3] += tsa - ts0;
+    prof_acc[1] += ts2 - ts1, prof_acc[2] += ts3 - ts2;
     prof_acc[4] += 1ull, prof_acc[5] += (unsigned long long)n_vis_prof;
 #endif
     // ---- the next round, and its loads --------------------------------------------------------------------------------------
@@ -666,6 +707,8 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
             next_claim = atomicAdd(queue, 1u);
     }
     stage_issue();
+    ++round;
+    setup_round();
     } // round
     } // any item at all
 #ifdef GWBP_STAMPS

@@ -125,3 +125,11 @@ def test_inline_asm_vmem_bases_come_from_the_scalar_alu(tmp_path):
         subprocess.check_call([hipcc, *flags, "-o", str(out), os.path.join(_lib.CSRC, f"{name}.hip")],
                               stderr=subprocess.DEVNULL)
         assert check_asm_hazards.scan(str(out)) == []
+        if name == "scatter_wide":
+            # The 256-channel kernel's register ALLOCATION decides how many front-stage waves fit beside it on a SIMD, and the
+            # step time with it (scatter_wide.hip, "REGISTER BUDGET": 104 allocated = one 64-register front wave per SIMD is
+            # the measured optimum; 120 shuts the front stage out until the kernel ends).  Both instantiations must ask for
+            # 97..104 registers.
+            txt = out.read_text()
+            found = re.findall(r"k_scatter_wideILb([01])E\S*\.num_vgpr, (\d+)", txt)
+            assert len(found) == 2 and all(97 <= int(n) <= 104 for _, n in found), found
