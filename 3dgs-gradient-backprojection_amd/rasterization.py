@@ -172,6 +172,27 @@ class _Rasterize(torch.autograd.Function):
         return (v_colors,) + (None,) * 10
 
 
+class _OneCameraBatch(torch.Tensor):
+    """render_colors [1,H,W,D] of a one-camera call.  The reference takes `output_for_grad[0]` of it and back-propagates
+    (backproject.py:127-129,145-147): autograd's backward of that select is a zero-filled [1,H,W,D] plus a copy of the
+    [H,W,D] gradient into it -- 7 GB of traffic per view at C2 for an axis of length one.  `batch[0]` of this class hands back
+    the [H,W,D] tensor the batch IS a view of (same storage, same autograd history, no extra node); every other index and
+    every torch op behaves as on a plain tensor and returns plain tensors."""
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def __getitem__(self, idx):
+        cam0 = getattr(self, "_camera0", None)
+        if cam0 is not None and type(idx) is int and idx in (0, -1):
+            return cam0
+        return super().__getitem__(idx)
+
+
+def one_camera_batch(render: torch.Tensor) -> torch.Tensor:
+    batch = render[None].as_subclass(_OneCameraBatch)
+    batch._camera0 = render
+    return batch
+
+
 class LazyMeta(dict):
     """meta dict of gsplat.rasterization (packed=True layout); the packed index tensors are materialised on
     first access because building them (nonzero) synchronises the host."""
@@ -283,5 +304,5 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     if want_meta:
         meta._opac = opacities
     if C_ == 1:  # (no copy of a 3.5 GB render: a view with the camera axis in front)
-        return outs[0][None], alphas[0][None], meta
+        return one_camera_batch(outs[0]), alphas[0][None], meta
     return torch.stack(outs), torch.stack(alphas), meta

@@ -28,6 +28,25 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+def committed_traffic(config, scatter_kernel, tfile=None):
+    """(HBM bytes per launch, where they come from, vector instructions per launch) of `scatter_kernel` at `config` from the
+    committed rocprofv3 --pmc passes (profiles/traffic.json, written by tools/make_traffic.py), or (None, None, None) when the
+    file holds no passes of THIS kernel: the counters of another kernel are not this kernel's traffic.  Names are compared
+    without namespace and template arguments (`gwbp::k_scatter_wide<false>` is `k_scatter_wide`)."""
+    def bare(name):
+        return str(name).split(" ")[0].split("<")[0].split("::")[-1]
+    tfile = tfile or os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tfile)).get(config, {})
+    except (OSError, ValueError):
+        return None, None, None
+    if not tj.get("scatter_kernel") or bare(tj["scatter_kernel"]) != bare(scatter_kernel):
+        return None, None, None
+    return (tj.get("scatter_hbm_bytes_per_launch"),
+            "profiles/traffic.json (" + str(tj.get("source", "rocprofv3 --pmc, earlier run")) + ")",
+            tj.get("scatter_valu_wave_instructions"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,18 +350,7 @@ def main():
                            else "k_blend<kFused>") + " (blend + scatter in one kernel, no weight store)" if fused_small else
                           "k_scatter_wide" if scatter_choice == "wide" else
                           "k_scatter_full" if (D % 128 == 0 or D <= 64) else "k_scatter")
-        traffic, traffic_source, valu_insts = None, None, None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile)).get(args.config, {})
-                # only the counters of THIS kernel: the file names the kernel its passes profiled
-                if str(tj.get("scatter_kernel", "")).split("::")[-1] == scatter_kernel.split(" ")[0].split("<")[0]:
-                    traffic = tj.get("scatter_hbm_bytes_per_launch")
-                    valu_insts = tj.get("scatter_valu_wave_instructions")
-                    traffic_source = "profiles/traffic.json (" + str(tj.get("source", "rocprofv3 --pmc, earlier run")) + ")"
-            except Exception:
-                traffic = None
+        traffic, traffic_source, valu_insts = committed_traffic(args.config, scatter_kernel)
         out = {
             "metric": "Gaussian-pixel-features/sec", "value": total_pairs * D / elapsed,
             "unit": "Gaussian-pixel-features/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -155,3 +155,59 @@ def test_bench_starts_its_own_ranks_for_gpus_n(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--total-views", "9"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_finds_the_committed_counters_of_the_kernel_it_timed(tmp_path):
+    """bench.py's `roofline.traffic` comes from profiles/traffic.json and only when that file's passes profiled the kernel
+    the run timed: the file holds rocprof's names (namespace, template arguments), the bench its own short ones."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f = tmp_path / "traffic.json"
+    f.write_text(json.dumps({"C2": {"scatter_kernel": "gwbp::k_scatter_wide<false>", "scatter_hbm_bytes_per_launch": 12.0,
+                                    "scatter_valu_wave_instructions": 5.0, "source": "x"},
+                             "C5": {"scatter_kernel": "gwbp::k_blend<2>", "scatter_hbm_bytes_per_launch": 3.0}}))
+    assert bench.committed_traffic("C2", "k_scatter_wide", str(f)) == (12.0, "profiles/traffic.json (x)", 5.0)
+    assert bench.committed_traffic("C2", "k_scatter_full", str(f)) == (None, None, None)   # another kernel's counters
+    assert bench.committed_traffic("C5", "k_blend<kFused> (blend + scatter in one kernel, no weight store)", str(f))[0] == 3.0
+    assert bench.committed_traffic("C4", "k_scatter_full", str(f)) == (None, None, None)   # no passes for this config
+    assert bench.committed_traffic("C2", "k_scatter_wide", str(tmp_path / "absent.json")) == (None, None, None)
+    # the committed file matches the kernels the default pipeline picks at the three bench configurations
+    for cfg, kern in (("C2", "k_scatter_wide"), ("C4", "k_scatter_full"), ("C5", "k_blend<kFused>")):
+        assert bench.committed_traffic(cfg, kern)[0] > 0, cfg
+
+
+def test_one_camera_batch_indexes_without_a_select_backward():
+    """rasterization() hands a one-camera render back as [1,H,W,D]; the reference back-propagates through
+    `output_for_grad[0]` (backproject.py:127-129).  That index must return the [H,W,D] tensor the batch is a view of --
+    autograd's select backward would zero-fill and copy a whole [1,H,W,D] per view -- with the gradients of every way of
+    indexing unchanged, and everything else a plain tensor."""
+    from gsbp_amd.rasterization import one_camera_batch
+    w = torch.randn(5, 4, 3)
+
+    def fresh():
+        leaf = torch.randn(5, 4, 3, requires_grad=True)
+        render = leaf * 2
+        return leaf, render, one_camera_batch(render)
+
+    leaf, render, batch = fresh()
+    assert batch.shape == (1, 5, 4, 3) and batch.requires_grad and batch[0] is render and batch[-1] is render
+    assert batch.data_ptr() == render.data_ptr()
+    for index in (lambda b: b[0], lambda b: b[-1], lambda b: b[0:1], lambda b: b, lambda b: b.squeeze(0), lambda b: b[0, :, :],
+                  lambda b: b.sum(0), lambda b: torch.cat([b, b])[1]):
+        leaf, _, batch = fresh()
+        (index(batch) * w).sum().backward()
+        assert torch.equal(leaf.grad, 2 * w)
+    leaf, render, batch = fresh()
+    (batch[0] * w).sum().backward()  # the reference's form: no SelectBackward between the product and the render
+    assert "Select" not in type(batch[0].grad_fn).__name__ and batch[0].grad_fn is render.grad_fn
+    for plain in (batch * 1, batch[0:1], batch.detach(), batch.clone(), batch.sum(), batch[0, 1]):
+        assert type(plain) is torch.Tensor
+    with pytest.raises(IndexError):
+        batch[1]
+    with torch.no_grad():  # one storage: an in-place change of the batch is a change of the camera's render
+        batch.mul_(0)
+    assert float(render.detach().abs().max()) == 0.0

@@ -59,4 +59,5 @@ print(f"reference loop through the shim: {sync_time(ref_view):.2f} ms/view", flu
 
 F = torch.zeros(N, D, device=dev); d = torch.zeros(N, device=dev)
 eng2 = gsbp_amd.Engine(N, W, H, device=dev, tight_binning=True)
+eng2.set_narrow_scatter(D % 256 != 0)  # the kernel ViewPipeline picks at this D (an Engine starts narrow)
 print(f"fused backproject_view: {sync_time(lambda: eng2.backproject_view(view, means, quats, scales, opac, feats, F, d)):.2f} ms/view")
