@@ -248,6 +248,29 @@ class Engine:
                             "(set_narrow_scatter(False) BEFORE blend_weights): this view's headers hold no weight sums")
         self._call("gwbp_accumulate_d", *self._args(), C.byref(view), C.c_float(scale_d), ptr(d), self._stream())
 
+    def has_weight_sums(self) -> bool:
+        """The view in the workspace was blended with the 256-channel scatter kernel enabled: its records carry their weight
+        sums (accumulate_d, scatter_uniform)."""
+        return bool(self._halves)
+
+    def scatter_uniform(self, view, value: torch.Tensor, F: torch.Tensor) -> None:
+        """F[g, :] += value * sum_p w_g(p): the scatter of a map whose every entry is `value` (a 0-d float32 HIP tensor, read
+        on the device), from the per-record weight sums -- the backward of `render.sum()`, which is what the reference's
+        denominator pass asks for (backproject.py:145-147).  Needs has_weight_sums()."""
+        if not self._halves:
+            raise GwbpError("scatter_uniform needs a view blended with the 256-channel scatter kernel enabled "
+                            "(set_narrow_scatter(False) BEFORE blend_weights): this view's headers hold no weight sums")
+        if F.dtype != torch.float32 or not F.is_cuda or F.dim() != 2 or F.shape[0] != self.n:
+            raise GwbpError(f"F must be a float32 HIP tensor [{self.n},D]")
+        sums = torch.zeros(self.n, device=self.device, dtype=torch.float32)
+        saved = self.caps.flags  # (the flag says which kernel the NEXT blend serves; the sums of THIS view are there)
+        self.caps.flags = saved & ~_lib.FLAG_NARROW_SCATTER
+        try:
+            self.accumulate_d(view, sums)
+        finally:
+            self.caps.flags = saved
+        F.add_(sums[:, None] * value.to(torch.float32))
+
     def scatter(self, view, feats, F, d, scale_f=1.0, scale_d=1.0, upsample: Optional[str] = None):
         """F += scale_f * sum_p w feats[p], d += scale_d * sum_p w from the view's weight store.
 

@@ -124,14 +124,15 @@ class _Rasterize(torch.autograd.Function):
         # a backward with D % 256 == 0 channels goes through the 256-channel scatter kernel, which needs the blend's
         # half-tile lists: the flag must be in place before this view's blend
         eng.set_narrow_scatter(not (colors.requires_grad and D % 256 == 0))
-        proj, bins, alphas, st = _run_front(eng, view, means, quats, scales, opacities, D > 4, holder is not None,
-                                            want_store=need_store)
-        if D <= 4:  # RGB / RGB+D / depth: pixel-parallel rasteriser straight from the sorted tile lists
+        # the reference's harvesting pattern: an all-zero differentiable colour table whose render is only there to be
+        # back-propagated through (backproject.py:67-72,115-129,133-147) -- the render of zeros is zeros, for any D
+        harvest = colors.requires_grad and _is_zero_table(colors)
+        proj, bins, alphas, st = _run_front(eng, view, means, quats, scales, opacities, D > 4 or harvest,
+                                            holder is not None, want_store=need_store)
+        if harvest:
+            out = _zero_render(dev, view.height, view.width, D)  # (alphas: the blend's, kept with the front-stage result)
+        elif D <= 4:  # RGB / RGB+D / depth: pixel-parallel rasteriser straight from the sorted tile lists
             out, alphas = eng.render_pixels(view, colors.detach())
-        elif colors.requires_grad and _is_zero_table(colors):
-            # the reference's harvesting pattern: an all-zero differentiable colour table whose render is only there to be
-            # back-propagated through (backproject.py:67-72,115-129) -- the render of zeros is zeros
-            out = _zero_render(dev, view.height, view.width, D)
         else:
             out = eng.render(view, colors.detach())
         ctx.has_store = need_store
@@ -165,11 +166,21 @@ class _Rasterize(torch.autograd.Function):
         acc = leaf.grad if leaf is not None else None
         if (acc is not None and acc.dtype == torch.float32 and acc.shape == ctx.shape and acc.is_contiguous()
                 and acc.device == means.device and not torch.is_grad_enabled()):
-            eng.scatter(view, g_out, acc, None)
+            _scatter_grad(eng, view, g_out, acc)
             return (None,) * 11
         v_colors = torch.zeros(ctx.shape, device=means.device, dtype=torch.float32)
-        eng.scatter(view, g_out, v_colors, None)
+        _scatter_grad(eng, view, g_out, v_colors)
         return (v_colors,) + (None,) * 10
+
+
+def _scatter_grad(eng: Engine, view, g_out: torch.Tensor, acc: torch.Tensor) -> None:
+    """acc[g, :] += sum_p w_g(p) g_out[p, :].  The gradient of `render.sum()` is ONE value expanded over [H,W,D] (all strides
+    zero): its scatter is that value times the per-Gaussian weight sums, which a view blended for the 256-channel kernel
+    already holds per record (the reference's denominator pass, backproject.py:145-147, right after its 512-channel one)."""
+    if g_out.dim() == 3 and g_out.numel() > 0 and not any(g_out.stride()) and eng.has_weight_sums():
+        eng.scatter_uniform(view, g_out[0, 0, 0], acc)
+    else:
+        eng.scatter(view, g_out, acc, None)
 
 
 class _OneCameraBatch(torch.Tensor):

@@ -826,3 +826,50 @@ def test_c_abi_refuses_wide_scatter_of_a_narrow_blend_and_leaves_f_and_d_untouch
     assert float(dd.sum()) > 0
     scale = float(F2.norm(dim=1).max())
     assert float((F - F2).norm(dim=1).max()) <= 2e-5 * scale and float((dd - d2).abs().max()) <= 2e-5 * float(d2.max())
+
+
+def test_dropin_denominator_pass_from_the_weight_sums(orc, dev):
+    """The reference's second pass per view, `rasterization(zeros [N,3])[0][0].sum().backward()` (backproject.py:133-147),
+    through the drop-in right after a 256-channel pass of the same view: the render of the zero table is not computed (its
+    alphas are the blend's), and the backward of the sum -- one value expanded over [H,W,3] -- is that value times the
+    per-record weight sums the view already holds (Engine.scatter_uniform) instead of a scatter of a map of ones.  Both
+    against the explicit kernels, and the denominators against the oracle."""
+    from gsbp_amd import rasterization
+    from gsbp_amd.rasterization import get_engine
+    cfg, sc = scene_np("T1")
+    d, h = to_dev(sc, dev), npy(sc)
+    N, W, H = cfg.n_gaussians, cfg.width, cfg.height
+    args = (d["means"], d["quats"], d["scales"], d["opac"])
+    wide = torch.zeros(N, 256, device=dev, requires_grad=True)
+    table0 = torch.zeros(N, 3, device=dev, requires_grad=True)
+    out, _, _ = rasterization(*args, wide, d["vms"][0][None], d["K"][None], width=W, height=H)
+    (out[0] * syn.make_feature_map(cfg, 0, dim=256).to(dev)).sum().backward()
+    eng = get_engine(dev, N, W, H)
+    gen = eng.generation
+    out0, alpha0, _ = rasterization(*args, table0, d["vms"][0][None], d["K"][None], width=W, height=H)
+    assert eng.generation == gen and eng.has_weight_sums()  # the first pass's front stage, blended for the 256-channel kernel
+    assert out0.shape == (1, H, W, 3) and float(out0.abs().max()) == 0.0
+    (out0[0].sum() * 2.5).backward()  # (2.5: the expanded value is read, not assumed to be one)
+    got = table0.grad.clone()
+    # the explicit kernels on the same view: alphas of the pixel rasteriser, scatter of a materialised constant map
+    with torch.no_grad():
+        rgb = torch.rand(N, 3, device=dev)
+        _, alpha_px, _ = rasterization(*args, rgb, d["vms"][0][None], d["K"][None], width=W, height=H)
+    assert torch.allclose(alpha0, alpha_px, rtol=0, atol=2e-6)
+    eng2 = gsbp_amd.Engine(N, W, H, device=dev)
+    view, _, _ = _front(eng2, d, cfg, 0, want=False)
+    eng2.blend_weights(view)
+    assert not eng2.has_weight_sums()
+    with pytest.raises(gsbp_amd.GwbpError):
+        eng2.scatter_uniform(view, torch.tensor(1.0, device=dev), torch.zeros(N, 3, device=dev))
+    want = torch.zeros(N, 3, device=dev)
+    eng2.scatter(view, torch.full((H, W, 3), 2.5, device=dev), want, None)
+    scale = float(want.abs().max())
+    assert scale > 0 and float((got - want).abs().max()) <= 2e-5 * scale
+    assert torch.equal(got[:, 0], got[:, 1]) and torch.equal(got[:, 0], got[:, 2])
+    Fr, dr = np.zeros((N, 3), np.float64), np.zeros(N, np.float64)
+    orc.backproject_view(h["means"], h["quats"], h["scales"], h["opac"], h["vms"][0], h["K"], W, H,
+                         np.full((H, W, 3), 2.5, np.float32), Fr, dr)
+    assert dr.max() > 0
+    assert rel_row_err(got.cpu().numpy(), Fr) <= TOL
+    assert rel_row_err(got[:, :1].cpu().numpy() / 2.5, dr[:, None]) <= TOL

@@ -44,13 +44,19 @@ gf = torch.zeros(N, D, device=dev)
 gd = torch.zeros(N, device=dev)
 
 
-def ref_view(v=0):
+calls = [0]
+
+
+def ref_view():
+    v = calls[0] % vms.shape[0]  # a NEW view per call, as in the job: the shim's front stage (project, sort, blend) runs once
+    calls[0] += 1                # per view; the second rasterization() of the view finds its result in the workspace
     out, _, _ = rasterization(means, quats, scales, opac, colors_feats, vms[v][None], K[None], width=W, height=H)
     (out[0] * feats).sum().backward()
-    gf.add_(colors_feats.grad)
+    colors_feats_copy = colors_feats.grad.clone()  # (the reference's own statements, backproject.py:127-151, in its order)
     colors_feats.grad.zero_()
     out, _, _ = rasterization(means, quats, scales, opac, colors_0, vms[v][None], K[None], width=W, height=H)
     out[0].sum().backward()
+    gf.add_(colors_feats_copy)
     gd.add_(colors_0.grad[:, 0])
     colors_0.grad.zero_()
 
