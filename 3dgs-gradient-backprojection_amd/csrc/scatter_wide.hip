@@ -71,15 +71,9 @@ constexpr size_t kLdsBytes = kCtlOff + 32;
 #endif
 constexpr int kTail = GWBP_TAIL; // visits held back for the end of a round (0 = the table is in list order).  Measured with 16 / 32 /
                                  // 48 / 96: the kernel beside the front stage 6-8 % faster (the waves run out of work together), the
-                                 // front stage beside it 10 % slower, the step 3.62 -> 3.96 ms: off, like GWBP_HALFBATCH below
+                                 // front stage beside it 10 % slower, the step 3.62 -> 3.96 ms -- at a LARGER register allocation; neutral at the
+                                 // same one (profiles/r4_wide_ablation.txt, section D): off
 constexpr int kShortN = 16;      // ... chosen among the visits of at most this many entries
-#ifndef GWBP_HALFBATCH
-#define GWBP_HALFBATCH 0
-#endif
-constexpr bool kHalfBatch = GWBP_HALFBATCH != 0;
-#ifndef GWBP_BATCH_LOOP
-#define GWBP_BATCH_LOOP 0
-#endif
 constexpr u32 kNoPix = 640; // a "pixel" whose slab row lies beyond the 160 KB an LDS allocation can have: reads as 0
 
 // Structure-preserving ablations (make PROFILE=1 ABL=<bits> via tools/build_ablations.sh; results INVALID by design, never in
@@ -516,63 +510,44 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         // The batch is scheduled by hand (sched_barrier): all eight pixel indices are read into scalar registers BEFORE the
         // first address is formed and all eight weights before the first FMA -- left alone, hipcc chains readlane -> address ->
         // read through ONE scalar register and pays a hazard s_nop per pair (twice: addresses and FMAs).
-        // KB = 8: a full batch.  Two build options that were measured and are OFF:
-        //   GWBP_HALFBATCH=1   a vector whose last batch holds 1..4 entries ends with a HALF batch (KB = 4) instead of a batch
-        //                      padded to eight pairs with zero weights.  It removes ~1 % of the kernel's vector instructions (C2's
-        //                      remainders are mostly 5..8) and makes the kernel 6 % faster beside the front stage -- and the front
-        //                      stage 12 % slower beside it (k_radix_scatter 0.15 -> 0.55 ms per pass, k_project 0.1 -> 1.1 ms
-        //                      under overlap; wave priority, free CUs, the blend's workgroup shape and the visit table's LDS share
-        //                      were all ruled out as the cause): the step went from 3.62 to 4.0 ms.
-        //   GWBP_BATCH_LOOP=1  the batches as a run-time loop (v_readlane with the lane index in a scalar register): 12 KB of code
-        //                      instead of 20-28, built to test whether code size was what hurt the front; it was not, and the
-        //                      kernel alone went from 3.2 to 3.6 ms.
-#define GWBP_BATCH(B0, KB)                                                                                            \
+        // A batch is always eight pairs (zero weights pad the vector's tail).
+        //
+        // Five vector instructions per pair, two of them v_readlane.  Without those two the step beside the front stage would
+        // be 4 % shorter (3.61 -> 3.46 ms, an ablation that takes one readlane pair per batch: it is this kernel's VECTOR ISSUE
+        // the front stage competes for).  The way to get rid of them that was built and measured -- each wave writes its
+        // vector to a 512-byte LDS buffer and a ds_read_b128 with the same address in every lane hands four weights / four
+        // pixel indices to all lanes as vector registers (v_pk_fma_f32 takes the weight from there via op_sel; with the pixel
+        // reads issued a batch ahead no extra LDS round trip is exposed: 26-32 vector instructions per batch instead of 40)
+        // -- is parity-green and 6 % SLOWER alone, 4 % beside the front stage: an LDS instruction occupies the CU's LDS pipe
+        // for 4.2-5 cycles whatever its width and however many lanes share an address (tools/ubench_lds_broadcast.hip), the
+        // eight slab reads of a batch already keep it busy 35 of the batch's ~50 cycles, and four more reads per batch cost
+        // more than 14 fewer vector instructions save.  profiles/r4_wide_ablation.txt, section E.  Also measured and gone:
+        // half batches for the tails (neutral), a run-time batch loop (12 KB of code instead of 20: 3.2 -> 3.6 ms alone).
+#define GWBP_BATCH(B0)                                                                                                \
     {                                                                                                                 \
-        u32 px_[KB];                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < KB; ++j) px_[j] = readlane_u(ev.pix, (int)((B0) + j));                  \
+        u32 px_[kB];                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < kB; ++j) px_[j] = readlane_u(ev.pix, (int)((B0) + j));                  \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
-        _Pragma("unroll") for (int j = 0; j < KB; ++j) f[j] = lds_read_b128((px_[j] << 10) + row_base);               \
+        _Pragma("unroll") for (int j = 0; j < kB; ++j) f[j] = lds_read_b128((px_[j] << 10) + row_base);               \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
-        float w_[KB];                                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < KB; ++j) w_[j] = readlane_f(ev.w, (int)((B0) + j));                     \
+        float w_[kB];                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < kB; ++j) w_[j] = readlane_f(ev.w, (int)((B0) + j));                     \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
-        _Pragma("unroll") for (int j = 0; j < KB; ++j)                                                                \
+        _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                \
         {                                                                                                             \
             acc_lo = pk_fma(w_[j], f[j].xy, acc_lo);                                                                  \
             acc_hi = pk_fma(w_[j], f[j].zw, acc_hi);                                                                  \
         }                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     }
-#if GWBP_BATCH_LOOP
-        // first batch (always there: n >= 1), then the claim's descriptor read, then the rest
-        if (kHalfBatch && n <= 4u) {
-            GWBP_BATCH(0u, 4)
-        } else {
-            GWBP_BATCH(0u, 8)
-        }
-        after_first();
-#pragma unroll 1
-        for (u32 b0 = (u32)kB; b0 < n; b0 += (u32)kB) {
-            if (kHalfBatch && n - b0 <= 4u) {
-                GWBP_BATCH(b0, 4)
-            } else {
-                GWBP_BATCH(b0, 8)
-            }
-        }
-#else
 #pragma unroll
         for (int B = 0; B < 64 / kB; ++B) {
             if ((u32)kB * B >= n)
                 break;
-            if (kHalfBatch && n - (u32)kB * B <= 4u) {
-                GWBP_BATCH(kB * B, 4)
-            } else {
-                GWBP_BATCH(kB * B, 8)
-            }
+            GWBP_BATCH(kB * B)
             if (B == 0)
                 after_first();
         }
-#endif
 #undef GWBP_BATCH
     };
 
