@@ -37,16 +37,12 @@ def reduce_partials(F: torch.Tensor, d: torch.Tensor) -> None:
 
 
 def encode_features(eng: Engine, feats: torch.Tensor, encoder: torch.Tensor, **kw) -> torch.Tensor:
-    """backproject_compressed.py:127 for the DRIVER: the hand-written kernel (Engine.encode_map) for every shape it takes --
-    which includes the reference's 512 -> 16 encoder -- and, explicitly and only here, torch's library GEMM for encoders
-    outside its domain (K % 16 != 0, more than 16 outputs, strided channels).  Engine.encode_map itself never falls back."""
-    if Engine.can_encode_map(feats, encoder):
-        return eng.encode_map(feats, encoder, **kw)
-    stream = kw.get("stream")
-    if stream is None:
-        return feats @ encoder
-    with torch.cuda.stream(stream):
-        return feats @ encoder
+    """backproject_compressed.py:127 for the DRIVER: the hand-written kernel (Engine.encode_map), whose domain -- [H,W,K]
+    float32 maps with channel-contiguous 16-B aligned pixels, K % 16 == 0, K <= 2048, at most 16 outputs -- includes the
+    reference's 512 -> 16 encoder.  Anything else RAISES (Engine.encode_map's own error): the drivers never switch to a
+    library GEMM behind the caller's back.  Whoever wants one encodes in the feature function (`feats @ encoder`) and passes
+    encoder=None."""
+    return eng.encode_map(feats, encoder, **kw)
 
 
 def rows_per_rank(n: int, world: int) -> int:

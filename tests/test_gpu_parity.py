@@ -271,13 +271,21 @@ def test_fused_driver_matches_oracle_mean_and_encoder(orc, dev):
     ref, _, _, _ = orc.backproject_oracle(h["means"], h["quats"], h["scales"], h["opac"], h["vms"], h["K"], cfg.width,
                                           cfg.height, lambda v: feats_all[v].numpy(), cfg.feat_dim, reduction="mean")
     assert np.abs(out.cpu().numpy() - ref).max() <= TOL
-    enc = torch.randn(cfg.feat_dim, 16, generator=torch.Generator().manual_seed(7)) / cfg.feat_dim ** 0.5
+    # encoder (backproject_compressed.py:127): through the hand-written GEMM, whose domain wants K % 16 == 0 ...
+    K_in = 32
+    maps32 = [syn.make_feature_map(cfg, v, dim=K_in) for v in range(cfg.n_views)]
+    enc = torch.randn(K_in, 16, generator=torch.Generator().manual_seed(7)) / K_in ** 0.5
     out = gsbp_amd.create_feature_field(d["means"], d["quats"], d["scales"], d["opac"], d["vms"], d["K"], cfg.width,
-                                        cfg.height, lambda v: feats_all[v].to(dev), cfg.feat_dim,
-                                        encoder=enc.to(dev))
+                                        cfg.height, lambda v: maps32[v].to(dev), K_in, encoder=enc.to(dev))
     ref, _, _, _ = orc.backproject_oracle(h["means"], h["quats"], h["scales"], h["opac"], h["vms"], h["K"], cfg.width,
-                                          cfg.height, lambda v: (feats_all[v] @ enc).numpy(), 16)
+                                          cfg.height, lambda v: (maps32[v] @ enc).numpy(), 16)
     assert np.abs(out.cpu().numpy() - ref).max() <= TOL
+    # ... and a shape outside it (K = 24) is REFUSED by every schedule of the driver: no library GEMM behind the caller's back
+    enc24 = torch.randn(cfg.feat_dim, 16, generator=torch.Generator().manual_seed(7)).to(dev)
+    for kw in (dict(), dict(pipeline=False), dict(fuse_encoder=True)):
+        with pytest.raises(gsbp_amd.GwbpError, match="encode_map"):
+            gsbp_amd.create_feature_field(d["means"], d["quats"], d["scales"], d["opac"], d["vms"], d["K"], cfg.width,
+                                          cfg.height, lambda v: feats_all[v].to(dev), cfg.feat_dim, encoder=enc24, **kw)
 
 
 def test_empty_and_degenerate_inputs(dev):
