@@ -83,6 +83,8 @@ constexpr u32 kNoPix = 640; // a "pixel" whose slab row lies beyond the 160 KB a
 //   4  no slab staging
 //   8  with 1: only 3 of 8 visits flush that way (what merging 2 x 2 tile blocks would save)
 //  16  parks and resumes all use carry row 0 (no carry traffic beyond L2)
+//  64  every flush = plain stores into the record's OWN row of F (the write traffic of a store-then-sum scatter whose partial
+//      rows are summed by a later pass: tools/probe_store_then_sum.py)
 #if defined(GWBP_PROFILE) && defined(GWBP_ABL)
 constexpr int kAbl = GWBP_ABL;
 #else
@@ -622,7 +624,13 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
                 } else {
                     if (scale_f != 1.0f) // wave-uniform; the .sum() reduction of backproject.py:127 needs no scaling
                         acc_lo *= scale_f, acc_hi *= scale_f;
-                    if (!(kAbl & 1) || ((kAbl & 8) && (cur.gid & 7u) >= 3u)) {
+                    if (kAbl & 64) { // ablation: the record's partial row leaves with plain stores (same shape, same row)
+                        const u64 fb = sbase(f_base + (u64)cur.gid * (u64)((u32)D * 4u));
+                        store_c<0>(lane4, acc_lo.x, fb);
+                        store_c<256>(lane4, acc_lo.y, fb);
+                        store_c<512>(lane4, acc_hi.x, fb);
+                        store_c<768>(lane4, acc_hi.y, fb);
+                    } else if (!(kAbl & 1) || ((kAbl & 8) && (cur.gid & 7u) >= 3u)) {
                         const u64 fb = sbase(f_base + (u64)cur.gid * (u64)((u32)D * 4u));
                         atomic_f<0>(lane4, acc_lo.x, fb);
                         atomic_f<256>(lane4, acc_lo.y, fb);
