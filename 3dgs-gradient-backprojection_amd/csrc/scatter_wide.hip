@@ -83,6 +83,8 @@ constexpr u32 kNoPix = 640; // a "pixel" whose slab row lies beyond the 160 KB a
 //   4  no slab staging
 //   8  with 1: only 3 of 8 visits flush that way (what merging 2 x 2 tile blocks would save)
 //  16  parks and resumes all use carry row 0 (no carry traffic beyond L2)
+//  32  ONE v_readlane pair per batch of eight pairs: the other seven take pixel + j and the same weight from scalar registers
+//      (every LDS read, FMA and wait stays; 14 of a batch's 16 v_readlane go -- what entries fed through the scalar unit would save)
 //  64  every flush = plain stores into the record's OWN row of F (the write traffic of a store-then-sum scatter whose partial
 //      rows are summed by a later pass: tools/probe_store_then_sum.py)
 #if defined(GWBP_PROFILE) && defined(GWBP_ABL)
@@ -528,12 +530,14 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
 #define GWBP_BATCH(B0)                                                                                                \
     {                                                                                                                 \
         u32 px_[kB];                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < kB; ++j) px_[j] = readlane_u(ev.pix, (int)((B0) + j));                  \
+        _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                \
+            px_[j] = (kAbl & 32) && j ? px_[0] + (u32)j : readlane_u(ev.pix, (int)((B0) + j));                        \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
         _Pragma("unroll") for (int j = 0; j < kB; ++j) f[j] = lds_read_b128((px_[j] << 10) + row_base);               \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
         float w_[kB];                                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < kB; ++j) w_[j] = readlane_f(ev.w, (int)((B0) + j));                     \
+        _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                \
+            w_[j] = (kAbl & 32) && j ? w_[0] : readlane_f(ev.w, (int)((B0) + j));                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
         _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                \
         {                                                                                                             \

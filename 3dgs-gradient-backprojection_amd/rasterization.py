@@ -30,11 +30,35 @@ _ZERO_TABLES: Dict[int, Tuple] = {}
 _ZERO_RENDERS: Dict[Tuple, Tuple] = {}
 
 
+# rows of a table that are re-checked on EVERY call (see _is_zero_table)
+_SAMPLE_ROWS = 257
+
+
+def invalidate_zero_table_cache() -> None:
+    """Forget every cached "this colour table is all zero" verdict (and the cached zero renders).  Call it after writing into
+    a differentiable colour table through `.data`, a raw pointer or anything else that does not move the tensor's version
+    counter; in-place torch ops on the tensor itself need nothing."""
+    _ZERO_TABLES.clear()
+    _ZERO_RENDERS.clear()
+
+
+def _sample_is_zero(colors: torch.Tensor) -> bool:
+    n = colors.shape[0]
+    step = max(1, n // _SAMPLE_ROWS)
+    return not bool(colors.detach()[::step].any())
+
+
 def _is_zero_table(colors: torch.Tensor) -> bool:
+    """Is the differentiable colour table all zero (the reference's harvesting pattern, backproject.py:67-72)?  The full
+    reduction runs once per (tensor object, in-place version).  Writes that do not move the version counter (`.data`, raw
+    pointers: old-style optimisers, checkpoint loads) are caught by re-checking a strided sample of ~257 rows on every call
+    -- dense rewrites of the table always hit it; a write confined to rows outside the sample does not, which is what
+    `invalidate_zero_table_cache()` is for."""
     key = id(colors)
     hit = _ZERO_TABLES.get(key)
     if hit is not None and hit[0]() is colors and hit[1] == colors._version:
-        return hit[2]
+        if not hit[2] or _sample_is_zero(colors):
+            return hit[2]
     z = not bool(colors.detach().any())
     if len(_ZERO_TABLES) > 16:
         _ZERO_TABLES.clear()
@@ -43,10 +67,15 @@ def _is_zero_table(colors: torch.Tensor) -> bool:
 
 
 def _zero_render(dev, h: int, w: int, d: int) -> torch.Tensor:
+    """The all-zero [H,W,D] render of an all-zero table: ONE cached storage per device and shape, but a FRESH tensor object per
+    call.  autograd hangs the producing node on the returned tensor object itself: handing the same object out twice would
+    re-point the first call's output at the second call's node, and two harvest forwards alive before either backward() -- or
+    one call with C > 1 cameras -- would send every gradient to the last view's node.  `detach()` shares storage and version
+    counter (an in-place write through any handed-out alias is seen here and the buffer zeroed again) and nothing else."""
     key = (str(dev), h, w, d)
     hit = _ZERO_RENDERS.get(key)
     if hit is not None and hit[0]._version == hit[1]:
-        return hit[0]
+        return hit[0].detach()
     if hit is not None:
         hit[0].zero_()
         buf = hit[0]
@@ -55,7 +84,26 @@ def _zero_render(dev, h: int, w: int, d: int) -> torch.Tensor:
             _ZERO_RENDERS.pop(next(iter(_ZERO_RENDERS)))
         buf = torch.zeros(h, w, d, device=dev, dtype=torch.float32)
     _ZERO_RENDERS[key] = (buf, buf._version)
-    return buf
+    return buf.detach()
+
+
+def _accumulate_node(leaf: torch.Tensor):
+    """The AccumulateGrad node of a leaf (what .backward() runs to add into leaf.grad)."""
+    with torch.enable_grad():
+        return leaf.view_as(leaf).grad_fn.next_functions[0][0]
+
+
+def _grad_is_unobserved(leaf: torch.Tensor, node) -> bool:
+    """May the backward add straight into leaf.grad instead of returning a gradient?  Only when nobody can tell the
+    difference: the engine is going to run the leaf's AccumulateGrad node itself (a .backward() call; under
+    torch.autograd.grad() the gradient is captured and returned instead, and the engine query raises), and no tensor hook or
+    post-accumulate-grad hook is registered on the leaf."""
+    if getattr(leaf, "_backward_hooks", None) or getattr(leaf, "_post_accumulate_grad_hooks", None):
+        return False
+    try:
+        return bool(torch._C._will_engine_execute_node(node))
+    except RuntimeError:  # "... we are currently running autograd.grad()"
+        return False
 
 
 def get_engine(device, n: int, width: int, height: int) -> Engine:
@@ -143,6 +191,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.shape = colors.shape
         # the leaf whose .grad the backward may add into directly (see backward)
         ctx.leaf = weakref.ref(colors) if (colors.requires_grad and colors.is_leaf) else None
+        ctx.leaf_node = _accumulate_node(colors) if ctx.leaf is not None else None
         ctx.mark_non_differentiable(alphas)
         return out, alphas
 
@@ -161,12 +210,16 @@ class _Rasterize(torch.autograd.Function):
             _run_front(eng, view, means, quats, scales, opacities, False, False)
         # The reference keeps ONE grad tensor per colour table alive (it clones and zeroes it in place, backproject.py:130-131),
         # so a returned gradient would be ADDED to it by autograd: a 2 GB temporary, its memset and a 6 GB read-modify-write
-        # per view at C2.  The scatter kernel accumulates anyway: add straight into the leaf's .grad and hand autograd nothing.
+        # per view at C2.  The scatter kernel accumulates anyway: add straight into the leaf's .grad and hand autograd nothing
+        # -- but only where that cannot be observed (_grad_is_unobserved: a plain .backward(), no hooks on the leaf;
+        # torch.autograd.grad() and hooked leaves get the returned gradient).
         leaf = ctx.leaf() if ctx.leaf is not None else None
         acc = leaf.grad if leaf is not None else None
         if (acc is not None and acc.dtype == torch.float32 and acc.shape == ctx.shape and acc.is_contiguous()
-                and acc.device == means.device and not torch.is_grad_enabled()):
+                and acc.device == means.device and not torch.is_grad_enabled()
+                and _grad_is_unobserved(leaf, ctx.leaf_node)):
             _scatter_grad(eng, view, g_out, acc)
+            acc[:0].add_(0)  # the kernel wrote through data_ptr: move .grad's version counter like an in-place op would
             return (None,) * 11
         v_colors = torch.zeros(ctx.shape, device=means.device, dtype=torch.float32)
         _scatter_grad(eng, view, g_out, v_colors)

@@ -211,3 +211,88 @@ def test_one_camera_batch_indexes_without_a_select_backward():
     with torch.no_grad():  # one storage: an in-place change of the batch is a change of the camera's render
         batch.mul_(0)
     assert float(render.detach().abs().max()) == 0.0
+
+
+def test_zero_render_is_a_fresh_tensor_per_call_and_keeps_autograd_edges_apart():
+    """the cached all-zero render must not be ONE tensor object handed out by every harvest forward --
+    autograd hangs the producing node on the returned object, so a second apply() would re-point the first call's output at
+    the second call's node.  The helper returns a new object over the same storage each time; a toy Function that returns it
+    twice before either backward gets both gradients."""
+    import sys
+    rz = sys.modules["gsbp_amd.rasterization"]  # (the package attribute of that name is the function)
+    rz.invalidate_zero_table_cache()
+    a = rz._zero_render("cpu", 2, 3, 4)
+    b = rz._zero_render("cpu", 2, 3, 4)
+    assert a is not b and a.data_ptr() == b.data_ptr() and a.shape == (2, 3, 4)
+    a.add_(1.0)  # an in-place write through a handed-out alias is noticed: the next render is zero again
+    c = rz._zero_render("cpu", 2, 3, 4)
+    assert float(c.abs().max()) == 0.0
+
+    class Harvest(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, table, k):
+            ctx.k = k
+            return rz._zero_render("cpu", 2, 3, 4)
+
+        @staticmethod
+        def backward(ctx, g):
+            return torch.full((5,), float(ctx.k)) * g.sum(), None
+
+    t = torch.zeros(5, requires_grad=True)
+    o1, o2 = Harvest.apply(t, 1.0), Harvest.apply(t, 20.0)
+    assert o1 is not o2 and o1.grad_fn is not o2.grad_fn
+    (o1.sum() + o2.sum()).backward()
+    assert torch.equal(t.grad, torch.full((5,), 24.0 * 21.0))
+
+
+def test_direct_grad_path_is_taken_only_where_it_cannot_be_observed():
+    """the drop-in's backward adds straight into leaf.grad only under a plain .backward() on a leaf without
+    hooks; torch.autograd.grad() and hooked leaves must get a returned gradient."""
+    import sys
+    rz = sys.modules["gsbp_amd.rasterization"]  # (the package attribute of that name is the function)
+    seen = []
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            ctx.leaf, ctx.node = x, rz._accumulate_node(x)
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(rz._grad_is_unobserved(ctx.leaf, ctx.node))
+            return g * 2
+
+    x = torch.ones(3, requires_grad=True)
+    Probe.apply(x).sum().backward()
+    torch.autograd.grad(Probe.apply(x).sum(), x)
+    Probe.apply(x).sum().backward(inputs=[x])
+    h = x.register_hook(lambda g: g)
+    Probe.apply(x).sum().backward()
+    h.remove()
+    h = x.register_post_accumulate_grad_hook(lambda t: None)
+    Probe.apply(x).sum().backward()
+    h.remove()
+    Probe.apply(x).sum().backward()
+    assert seen == [True, False, True, False, False, True]
+
+
+def test_zero_table_verdict_is_rechecked_on_a_sample_and_can_be_invalidated():
+    """writes through .data do not move the version counter; a dense one is caught by the per-call sample,
+    a sparse one by invalidate_zero_table_cache()."""
+    import sys
+    rz = sys.modules["gsbp_amd.rasterization"]  # (the package attribute of that name is the function)
+    rz.invalidate_zero_table_cache()
+    t = torch.zeros(1000, 8, requires_grad=True)
+    assert rz._is_zero_table(t) and rz._is_zero_table(t)
+    v = t._version
+    t.data.add_(1.0)
+    assert t._version == v          # the blind spot of a (tensor, version) key ...
+    assert not rz._is_zero_table(t)  # ... which the sample closes for dense writes
+    t.data.zero_()
+    assert not rz._is_zero_table(t)  # (cached "non-zero" at this version: the safe side -- a full render, never a wrong one)
+    rz.invalidate_zero_table_cache()
+    assert rz._is_zero_table(t)
+    t.data[1, 0] = 3.0               # one row outside the sample: needs the explicit invalidation
+    rz.invalidate_zero_table_cache()
+    assert not rz._is_zero_table(t)
