@@ -12,8 +12,9 @@
 //     with a conservative 4-bit strip mask (which quarters the Gaussian can reach at all)
 //   per contributing (Gaussian, tile) RECORD: mask[q] = ballot(contributes in quarter q); the entries {w, pixel} of
 //     the four quarters are written back to back (ascending pixel order, lane rank = mbcnt, 8-B stores) into the
-//     wave's stream carved from a sharded global pool in pages of kPage entries, zero-padded to a multiple of 8
-//     per record, followed by one 64-B Header {gid, woff[q], counts, mask[q]} in list order.
+//     wave's stream carved from a sharded global pool in pages of kPage entries, padded with {0, kPadPix} to a multiple of 8
+//     per record (kHalves: per half-tile list, see below), followed by one 64-B Header {gid, woff[q], counts, mask[q]} in
+//     list order.
 //
 // Store size: 8 B per pair (+ padding) + 64 B per header (C2: ~0.75 GB + ~115 MB per view), written once, then read
 // by the scatter kernel once per 128-channel chunk through L2.
@@ -326,10 +327,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 }
                 continue;
             }
-            u32 cnt[4], base[4], total = 0;
+            // Entry layout of a record: quarters 0 | 1 back to back, then quarters 2 | 3 back to back.  kHalves: the second half
+            // starts on a multiple of kListPad entries (64 B), i.e. BOTH half-tile lists are padded -- k_scatter_wide fetches a
+            // half's entries eight at a time with s_load_dwordx16 and must find {0, kPadPix} behind the last real one.
+            u32 cnt[4], base[4], total = 0, mid_pad = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 cnt[q] = (u32)__popcll(m[q]);
+                if (WSUM && q == 2) {
+                    mid_pad = (0u - total) & (u32)(kListPad - 1);
+                    total += mid_pad;
+                }
                 base[q] = total;
                 total += cnt[q];
             }
@@ -363,6 +371,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 continue;
             }
             const u32 padded = (total + (kListPad - 1)) & ~(u32)(kListPad - 1);
+            const u32 end_pad = padded - total;
             if (padded > page_left) {
                 u32 old = 0;
                 if (lane == 0)
@@ -383,10 +392,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     e.w = w[q], e.pix = (u32)(q * 64 + lane);
                     store_pair_masked(m[q], wpool + (page_pos + base[q] + mbcnt(m[q])), e);
                 }
-                if ((u32)lane < padded - total) { // {0, 0} tail: the scatter loop needs no remainder handling
+                if ((u32)lane < mid_pad + end_pad) { // {0, kPadPix} behind each half (kStore: behind the record): no remainder handling
                     WPair z;
-                    z.w = 0.f, z.pix = 0u;
-                    wpool[page_pos + total + lane] = z;
+                    z.w = 0.f, z.pix = kPadPix;
+                    wpool[page_pos + ((u32)lane < mid_pad ? base[2] - mid_pad + lane : total + lane - mid_pad)] = z;
                 }
                 // only the 256-channel scatter path wants the record's weight sum (its visit loop has no room for d), hence the
                 // template parameter
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
             page_pos += padded;
             page_left -= padded;
-            npairs += total;
+            npairs += total - mid_pad;
         }
     }
     if (lane == 0) {

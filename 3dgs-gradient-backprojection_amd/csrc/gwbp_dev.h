@@ -22,7 +22,10 @@ constexpr int kTilePix = 256;
 constexpr int kPage = 1024;          // weight-pool page (pairs) grabbed per (tile, wave) stream
 constexpr int kQueues = 8;           // scatter work queues, one per XCD class (blockIdx % 8), 64 B apart, after the shard heads
 constexpr int kShards = 32;          // independently counted regions of the weight pool (one head word per 64-B line)
-constexpr int kListPad = 8;          // every record's entry list is zero-padded to a multiple of kListPad entries
+constexpr int kListPad = 8;          // every record's entry list is padded to a multiple of kListPad entries (kHalves: each half's)
+constexpr unsigned kPadPix = 640;    // "pixel" of a padding entry {0, kPadPix}: its slab row lies beyond the 160 KB an LDS allocation
+                                     // can have in the 256-channel kernel (1 KB rows), where an out-of-range read returns 0; every
+                                     // other consumer masks the padding by the quarters' counts
 constexpr int kSortItems = 4096;     // keys per sort block (256 threads x 16)
 constexpr int kScanBlock = 256;      // Gaussians per project/emit block
 
@@ -43,7 +46,12 @@ struct __attribute__((aligned(8))) WPair {
 
 // One per (Gaussian, tile) pair that contributes at least one weight.  mask[q] bit l <=> pixel q*64+l of the tile
 // (row-major 16x16) has a weight; the popc(mask[q]) entries of quarter q are contiguous at wpool[woff[q]..] in
-// ascending pixel order, followed by {0, 0} entries up to the next multiple of kListPad (woff[q] % 8 == 0).
+// ascending pixel order.  INVARIANTS the scatter kernels rely on: quarters 0 | 1 are back to back (woff[1] = woff[0] + cnt0) and
+// so are quarters 2 | 3; woff[0] % kListPad == 0; the record ends with {0, kPadPix} entries up to the next multiple of kListPad.
+// A store blended for the 256-channel kernel (k_blend<kHalves>) additionally pads the FIRST half: woff[2] % kListPad == 0 with
+// {0, kPadPix} entries between the halves (k_scatter_wide fetches a half's entries eight at a time); otherwise woff[2] =
+// woff[1] + cnt1.  A reader of the whole record as one run (k_scatter_full) takes woff[3] + cnt3 - woff[0] entries and drops
+// those with pix >= 256.
 // counts = cnt0 | cnt1 << 8 | cnt2 << 16 | cnt3 << 24 (cnt <= 64).
 struct __attribute__((aligned(64))) Header {
     u32 gid;

@@ -337,7 +337,9 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
         r.gid = uniform(hp->gid);
         r.woff = uniform(hp->woff[0]);
         const u32 c = uniform(hp->counts);
-        r.T = (c & 0xFFu) + ((c >> 8) & 0xFFu) + ((c >> 16) & 0xFFu) + (c >> 24);
+        // the record's entries as ONE run: all four quarters, plus the padding a store blended for the 256-channel kernel has
+        // between its halves (Header, gwbp_dev.h) -- those entries carry pix = kPadPix and are dropped below
+        r.T = uniform(hp->woff[3]) + (c >> 24) - r.woff;
         return r;
     };
     // slot s of the record's entry stream -> index into the weight pool
@@ -416,10 +418,11 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
                     break;
                 const u32 n = min(64u, R.T - 64u * j);
                 EV ev;
-                ev.w = ((u32)lane < n) ? e[j].w : 0.f; // clamped loads: zero the lanes past the list ...
+                const bool real = (u32)lane < n && e[j].pix < (u32)kTilePix; // (not a padding entry between the halves)
+                ev.w = real ? e[j].w : 0.f; // clamped loads: zero the lanes past the list ...
                 // ... and point them past the slab (an out-of-range LDS read returns 0): w = 0 times the record's last pixel
                 // would turn an inf feature there into NaN (0 x inf)
-                ev.pix = ((u32)lane < n) ? e[j].pix : kNoPix;
+                ev.pix = real ? e[j].pix : kNoPix;
                 wacc += ev.w;
                 run_vec(ev, n);
             }
@@ -427,8 +430,9 @@ __global__ __launch_bounds__(kThreads) void k_scatter_full(
                 const u32 n = min(64u, R.T - 64u * j);
                 const WPair wp = wpool[wslot(R, min(64 * j + lane, R.T - 1))];
                 EV ev;
-                ev.w = ((u32)lane < n) ? wp.w : 0.f;
-                ev.pix = ((u32)lane < n) ? wp.pix : kNoPix;
+                const bool real = (u32)lane < n && wp.pix < (u32)kTilePix;
+                ev.w = real ? wp.w : 0.f;
+                ev.pix = real ? wp.pix : kNoPix;
                 wacc += ev.w;
                 run_vec(ev, n);
             }

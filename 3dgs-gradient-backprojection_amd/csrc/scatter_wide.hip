@@ -26,11 +26,23 @@
 //     first batch; the descriptor read it enables completes under the rest of the visit.
 //   * Every VMEM operation of a visit addresses SGPR base + one of two per-lane constants (lane * 4 / 8): no vector
 //     address arithmetic, no 64-bit VGPR pairs.
-//   * One landing buffer: the entries (+ carry dwords) of the next visit are loaded a whole visit ahead, consumed by the
-//     selects that start a visit, and only then re-targeted.  One copy of the visit code per pass (the kernel's code
-//     shrank from 51 KB to a third: front-stage kernels share the instruction cache).
-// Every VMEM instruction of a visit is unconditional WITHIN a pass, so the counted s_waitcnt in front of a visit's entries
-// is exact: a visit issues its loads (2 in the top pass, 2 + 4 carry dwords in the bottom pass) and 4 flush operations
+//   * One landing buffer: the carry dwords of the next visit (and the L2 warm-up of its entries) are loaded a whole visit
+//     ahead, consumed by the selects that start a visit, and only then re-targeted.  One copy of the visit code per pass.
+// Round 5: the entries reach the arithmetic through the SCALAR unit.  A batch of eight pairs is ONE s_load_dwordx16 into an
+// aligned SGPR tuple -- entry j = the SGPR pair {w, pix}: v_pk_fma_f32 reads the weight and v_lshl_add_u32 the pixel straight from
+// it -- so a pair costs 3 vector instructions (address, two packed FMAs) where rounds 1-4 spent 5 (two v_readlane in front).  The
+// structure-preserving ablation had priced the two v_readlane at 5 % of the C2 step, 10 % together with fewer flushes
+// (profiles/r5_combined_ablation.txt); round 1 had found scalar-fed entries latency-bound (8.9 ms).  What makes them stream
+// (tools/ubench_sload.hip): (i) the visit's lines are pulled into L2 a whole visit ahead by a one-dword-per-line vector load, so
+// the scalar load is an L2 hit; (ii) a rolling double buffer of two fixed SGPR tuples, s[68:83] and s[84:99], which the
+// compiler never allocates (amdgpu_num_sgpr(76) keeps it inside s0..s67; a CPU test scans the assembly): the load of batch
+// b + 1 -- at the end of a visit: the NEXT visit's first batch -- goes out at the top of batch b and has landed when batch b's last
+// FMA has waited for lgkmcnt(0); nothing of the stream is ever in flight outside a batch's asm block.  The blend pads both
+// half-tile lists of a record to eight entries with {0, kPadPix} (gwbp_dev.h: Header), so a batch needs no remainder handling.
+// The batch loop is a run-time loop over two copies of the block (tuple A -> B, B -> A): 6 KB of code where the unrolled
+// v_readlane form had 20.
+// Every VMEM instruction of a visit is unconditional WITHIN a pass, so the counted s_waitcnt in front of a visit's carry dwords
+// is exact: a visit issues its loads (1 warm-up in the top pass, 1 + 4 carry dwords in the bottom pass) and 4 flush operations
 // (atomics, or the 4 stores that park a spanning record).  The denominator d is not accumulated here: the blend adds
 // every record's weight sum to d itself (gwbp_blend_weights_d), or k_accum_d (scatter.hip) does from the headers.
 
@@ -74,7 +86,7 @@ constexpr int kTail = GWBP_TAIL; // visits held back for the end of a round (0 =
                                  // front stage beside it 10 % slower, the step 3.62 -> 3.96 ms -- at a LARGER register allocation; neutral at the
                                  // same one (profiles/r4_wide_ablation.txt, section D): off
 constexpr int kShortN = 16;      // ... chosen among the visits of at most this many entries
-constexpr u32 kNoPix = 640; // a "pixel" whose slab row lies beyond the 160 KB an LDS allocation can have: reads as 0
+static_assert(((size_t)kPadPix - (size_t)kHalfPix) * 1024u >= 160u * 1024u, "a padding entry's slab row must lie beyond any LDS allocation in both passes");
 
 // Structure-preserving ablations (make PROFILE=1 ABL=<bits> via tools/build_ablations.sh; results INVALID by design, never in
 // the product library): compile-time, so every build keeps the visit's VMEM count and hence its counted waits.
@@ -83,8 +95,8 @@ constexpr u32 kNoPix = 640; // a "pixel" whose slab row lies beyond the 160 KB a
 //   4  no slab staging
 //   8  with 1: only 3 of 8 visits flush that way (what merging 2 x 2 tile blocks would save)
 //  16  parks and resumes all use carry row 0 (no carry traffic beyond L2)
-//  32  ONE v_readlane pair per batch of eight pairs: the other seven take pixel + j and the same weight from scalar registers
-//      (every LDS read, FMA and wait stays; 14 of a batch's 16 v_readlane go -- what entries fed through the scalar unit would save)
+//  32  (rounds 4-5, v_readlane form of the batch loop only: one v_readlane pair per batch of eight pairs -- what entries fed
+//      through the scalar unit would save.  It priced the rewrite above, profiles/r5_combined_ablation.txt; no effect any more)
 //  64  every flush = plain stores into the record's OWN row of F (the write traffic of a store-then-sum scatter whose partial
 //      rows are summed by a later pass: tools/probe_store_then_sum.py)
 #if defined(GWBP_PROFILE) && defined(GWBP_ABL)
@@ -101,54 +113,28 @@ struct Visit { // wave-uniform description of one (record, half) visit
     u32 row;  // the record's index in its tile's header list
 };
 
-__device__ __forceinline__ float readlane_f(float v, int l)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-__device__ __forceinline__ u32 readlane_u(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
-// 16-B LDS read at a BYTE ADDRESS (the slab is the start of the kernel's only LDS allocation): lets the compiler fold
-// the whole address into one v_lshl_add_u32
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4_t lds_read_b128(u32 a)
-{
-#if __HIP_DEVICE_COMPILE__
-    return *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t *>((size_t)a);
-#else
-    (void)a;
-    return f32x4_t{0.f, 0.f, 0.f, 0.f};
-#endif
-}
-// two FMAs as ONE v_pk_fma_f32 on an aligned register pair (left to the SLP vectoriser, scalar fmaf calls were paired
-// across the halves of a float4 -- (y, z) and (w, x) -- at the price of two v_mov per v_pk_fma_f32)
-__device__ __forceinline__ f32x2_t pk_fma(float w, f32x2_t f, f32x2_t acc)
-{
-    return __builtin_elementwise_fma(f32x2_t{w, w}, f, acc);
-}
-
-struct EV { // entries 64j .. 64j+63 of a visit, one per lane
-    float w;
-    u32 pix;
-};
-struct Land { // what a visit prefetches: two entry vectors and the four carry dwords of this lane
-    EV e[2];
+struct Land { // what a visit prefetches a whole visit ahead: the L2 warm-up of its entries (value unused) and its carry dwords
+    u32 warm;
     float c[4];
 };
 // All VMEM of the visit loop: address = SGPR pair + per-lane 32-bit offset + immediate.  Tied operands ("+v"): the load
 // must land in the registers the struct lives in (scatter_full.hip explains what happens otherwise).
-// `lanes` = the lanes that hold an entry of the visit: the others issue no request (they would fetch the next records' entries:
-// 1 KB per visit whatever its length, +1.1 GB of fabric reads per C2 view) and keep their old register contents, which the
-// selects that consume the landing buffer mask out anyway.  The instruction is issued either way: the counted waits stand.
-template <int OFF>
-__device__ __forceinline__ void load_e(EV &dst, u32 voff, u64 base, u64 lanes)
+// The L2 warm-up of a visit's entries: lane k touches byte 128 k of the visit's run, `lanes` = the lines the run can reach.  The
+// loaded dword is never used -- the entries are consumed through scalar loads, which must find their lines in L2 -- but the
+// instruction is issued for every visit (the counted waits stand) and its register stays reserved until it has landed.
+__device__ __forceinline__ void load_warm(u32 &dst, u32 lane4, u64 base, u64 lanes)
 {
     u64 saved;
-    asm volatile("s_mov_b64 %1, exec\n\t"
+    u32 voff;
+    asm volatile("v_lshlrev_b32 %2, 5, %3\n\t"
+                 "s_mov_b64 %1, exec\n\t"
                  "s_mov_b64 exec, %5\n\t"
-                 "global_load_dwordx2 %0, %2, %3 offset:%4\n\t"
+                 "global_load_dword %0, %2, %4\n\t"
                  "s_mov_b64 exec, %1"
-                 : "+v"(*reinterpret_cast<float2 *>(&dst)), "=&s"(saved)
-                 : "v"(voff), "s"(base), "n"(OFF), "s"(lanes)
+                 : "+v"(dst), "=&s"(saved), "=&v"(voff)
+                 : "v"(lane4), "s"(base), "s"(lanes)
                  : "memory");
 }
 // sc1: served by L2, never by this CU's L1 (the row was written by another wave of this workgroup one pass earlier)
@@ -181,11 +167,65 @@ __device__ __forceinline__ void wait_info(u32 &a, u32 &b)
 template <int N>
 __device__ __forceinline__ void wait_land(Land &x)
 {
-    asm volatile("s_waitcnt vmcnt(%6)"
-                 : "+v"(*reinterpret_cast<float2 *>(&x.e[0])), "+v"(*reinterpret_cast<float2 *>(&x.e[1])),
-                   "+v"(x.c[0]), "+v"(x.c[1]), "+v"(x.c[2]), "+v"(x.c[3])
-                 : "n"(N)
-                 : "memory");
+    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(x.warm), "+v"(x.c[0]), "+v"(x.c[1]), "+v"(x.c[2]), "+v"(x.c[3]) : "n"(N) : "memory");
+}
+// ---- the scalar entry stream -------------------------------------------------------------------------------------------
+// Two fixed SGPR tuples (the kernel is compiled with amdgpu_num_sgpr(76): hipcc stays inside s0..s67) and the batch buffer
+// v[72:103] (eight float4; named as clobbers, so hipcc keeps nothing alive there across a batch and is free to use the
+// registers between batches -- the slab staging lands in them).
+#define GWBP_SA 68
+#define GWBP_SB 84
+#define GWBP_TUPLES                                                                                                   \
+    "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",  \
+        "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+#define GWBP_FREGS                                                                                                    \
+    "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89",  \
+        "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103"
+#define GWBP_STR2(x) #x
+#define GWBP_STR(x) GWBP_STR2(x)
+// entry j of tuple T: weight = s[T + 2j] (read as the aligned pair s[T + 2j : T + 2j + 1] with op_sel_hi 0), pixel = s[T + 2j + 1]
+#define GWBP_RD(T, j, v0)                                                                                             \
+    "v_lshl_add_u32 %[t], s[" GWBP_STR(T) "+" #j "*2+1], 10, %[rb]\n\tds_read_b128 v[" #v0 ":" #v0 "+3], %[t]\n\t"
+#define GWBP_FM(T, j, v0, cnt)                                                                                        \
+    "s_waitcnt lgkmcnt(" #cnt ")\n\t"                                                                                  \
+    "v_pk_fma_f32 %[lo], s[" GWBP_STR(T) "+" #j "*2:" GWBP_STR(T) "+" #j "*2+1], v[" #v0 ":" #v0 "+1], %[lo] op_sel_hi:[0,1,1]\n\t"   \
+    "v_pk_fma_f32 %[hi], s[" GWBP_STR(T) "+" #j "*2:" GWBP_STR(T) "+" #j "*2+1], v[" #v0 "+2:" #v0 "+3], %[hi] op_sel_hi:[0,1,1]\n\t"
+// One batch: eight pairs from tuple CUR while the load of the next batch flies into tuple NXT.  lgkmcnt: the scalar load may
+// return at any time, LDS reads return in order, so "at most 7 - k outstanding" still proves read k complete whatever else
+// (the scalar load, an older claim or table read) is in flight; the last wait is lgkmcnt(0): the next tuple has landed too.
+#define GWBP_BATCH_ASM(CUR, NXT)                                                                                      \
+    "s_load_dwordx16 s[" GWBP_STR(NXT) ":" GWBP_STR(NXT) "+15], %[nx], 0x0\n\t"                                         \
+    GWBP_RD(CUR, 0, 72) GWBP_RD(CUR, 1, 76) GWBP_RD(CUR, 2, 80) GWBP_RD(CUR, 3, 84)                                     \
+    GWBP_RD(CUR, 4, 88) GWBP_RD(CUR, 5, 92) GWBP_RD(CUR, 6, 96) GWBP_RD(CUR, 7, 100)                                    \
+    GWBP_FM(CUR, 0, 72, 7) GWBP_FM(CUR, 1, 76, 6) GWBP_FM(CUR, 2, 80, 5) GWBP_FM(CUR, 3, 84, 4)                         \
+    GWBP_FM(CUR, 4, 88, 3) GWBP_FM(CUR, 5, 92, 2) GWBP_FM(CUR, 6, 96, 1) GWBP_FM(CUR, 7, 100, 0)
+// par = 0: the batch sits in tuple A and the next one goes to B; par = 1: the other way round.  ONE asm statement with a scalar
+// branch inside: as two statements in an if / else hipcc gave each its own copy of the accumulators and moved them there and
+// back around every batch (4 v_mov_b64 per batch).
+__device__ __forceinline__ void batch_run(u32 par, u64 next, u32 row_base, f32x2_t &lo, f32x2_t &hi)
+{
+    u32 t;
+    asm volatile("s_cmp_lg_u32 %[par], 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 GWBP_BATCH_ASM(GWBP_SA, GWBP_SB)
+                 "s_branch 2f\n"
+                 "1:\n\t"
+                 GWBP_BATCH_ASM(GWBP_SB, GWBP_SA)
+                 "2:"
+                 : [lo] "+v"(lo), [hi] "+v"(hi), [t] "=&v"(t)
+                 : [nx] "s"(next), [rb] "v"(row_base), [par] "s"(par)
+                 : GWBP_TUPLES, GWBP_FREGS, "scc", "memory");
+}
+// the first batch of a pass: nothing to overlap it with (one exposed L2 round trip per wave and pass)
+template <int P>
+__device__ __forceinline__ void batch_prime(u64 first)
+{
+    if constexpr (P == 0)
+        asm volatile("s_load_dwordx16 s[" GWBP_STR(GWBP_SA) ":" GWBP_STR(GWBP_SA) "+15], %0, 0x0\n\ts_waitcnt lgkmcnt(0)" ::"s"(first)
+                     : GWBP_TUPLES, "memory");
+    else
+        asm volatile("s_load_dwordx16 s[" GWBP_STR(GWBP_SB) ":" GWBP_STR(GWBP_SB) "+15], %0, 0x0\n\ts_waitcnt lgkmcnt(0)" ::"s"(first)
+                     : GWBP_TUPLES, "memory");
 }
 // one lane, one LDS atomic, NOT waited for (the wave-aggregation sequence hipcc wraps around a single-lane atomicAdd is ~8
 // instructions and waits at once)
@@ -222,7 +262,7 @@ __device__ __forceinline__ u64 sbase(u64 x)
 constexpr int kFlush = 4; // VMEM flush operations per visit
 
 template <bool BILINEAR> // a bilinear low-resolution map (gwbp_scatter_bilinear) has a staging loop of its own: own instantiation
-__global__ __launch_bounds__(kThreads) void k_scatter_wide(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void k_scatter_wide(
     ViewDev V, int n_chunks, const u32 *__restrict__ tile_offsets, const u32 *__restrict__ hdr_count,
     const Header *__restrict__ headers, const WPair *__restrict__ wpool, FeatMap M, int D, float scale_f,
     float *__restrict__ F, u32 *__restrict__ queues, float *__restrict__ carry_all, Counters *__restrict__ ctr)
@@ -479,18 +519,14 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
         r.row = ns >> 16;
         return r;
     };
-    // exactly 2 (top pass) / 6 (bottom pass) VMEM loads: the top pass never resumes a record
+    const u64 wp_base = uniform64(reinterpret_cast<u64>(wpool));
+    auto entries_of = [&](const Visit &R) __attribute__((always_inline)) -> u64 { return wp_base + ((u64)R.off << 3); };
+    // exactly 1 (top pass) / 5 (bottom pass) VMEM loads: the top pass never resumes a record
     auto prefetch = [&](const Visit &R, Land &x, auto bottom) __attribute__((always_inline)) {
-        const u64 eb = sbase(reinterpret_cast<u64>(wpool) + ((u64)R.off << 3));
-        const u32 n0 = min(R.n, 64u), n1 = R.n - n0;
-        // lane * 8, formed here and not kept: ONE register decides whether the kernel is allocated 80 or 88 VGPRs per lane
-        // (next_free_vgpr <= 79 / >= 80), i.e. whether three or two 64-register front-stage waves fit on a SIMD beside the four
-        // scatter waves -- at 88 the front stage beside the kernel runs 10 % slower and the step goes from 3.65 to 3.97 ms
-        // (the asm keeps hipcc from hoisting the shift out of the visit loop)
-        u32 lane8;
-        asm volatile("v_lshlrev_b32 %0, 1, %1" : "=v"(lane8) : "v"(lane4));
-        load_e<0>(x.e[0], lane8, eb, n0 == 64u ? ~0ull : (1ull << n0) - 1ull);
-        load_e<512>(x.e[1], lane8, eb, n1 == 64u ? ~0ull : (1ull << n1) - 1ull);
+        const u64 eb = sbase(entries_of(R));
+        // the run is 8 n bytes from a 64-byte boundary: it can reach into ceil((8 n + 64) / 128) lines of 128 B (1..9)
+        const u32 nl = (R.n * 8u + 64u + 127u) >> 7;
+        load_warm(x.warm, lane4, eb, (1ull << nl) - 1ull);
         if constexpr (decltype(bottom)::value) {
             // carry dwords of this lane (non-spanning records: row 0, value ignored -- the count must stay exact)
             const u64 cr = sbase(carry + ((u64)((R.span && !(kAbl & 16)) ? R.row : 0u) << 10));
@@ -502,66 +538,13 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
     };
 
     f32x2_t acc_lo, acc_hi; // channels {l, l + 64} and {l + 128, l + 192} of the record's sums
-    // n in 1..64 entries held by lanes 0..n-1 of ev (lanes >= n: w = 0, pix = kNoPix)
-    auto run_vec = [&](const EV &ev, u32 n, auto &&after_first) __attribute__((always_inline)) {
-        // ONE batch of 8 float4 in flight (32 VGPRs): the other waves of the SIMD cover the LDS latency between the
-        // eight reads and the first FMA.
-        constexpr int kB = 8;
-        f32x4_t(&f)[kB] = fbuf;
-        // LDS address = slab row of the pixel + this lane's 16 B: ONE v_lshl_add_u32 per pair straight from the
-        // v_readlane'd pixel index (row_base already carries -128 rows in the bottom pass, where every real entry has
-        // pix >= 128; masked lanes point at kNoPix, far beyond any LDS allocation -- an out-of-range LDS read returns 0).
-        // The batch is scheduled by hand (sched_barrier): all eight pixel indices are read into scalar registers BEFORE the
-        // first address is formed and all eight weights before the first FMA -- left alone, hipcc chains readlane -> address ->
-        // read through ONE scalar register and pays a hazard s_nop per pair (twice: addresses and FMAs).
-        // A batch is always eight pairs (zero weights pad the vector's tail).
-        //
-        // Five vector instructions per pair, two of them v_readlane.  Without those two the step beside the front stage would
-        // be 4 % shorter (3.61 -> 3.46 ms, an ablation that takes one readlane pair per batch: it is this kernel's VECTOR ISSUE
-        // the front stage competes for).  The way to get rid of them that was built and measured -- each wave writes its
-        // vector to a 512-byte LDS buffer and a ds_read_b128 with the same address in every lane hands four weights / four
-        // pixel indices to all lanes as vector registers (v_pk_fma_f32 takes the weight from there via op_sel; with the pixel
-        // reads issued a batch ahead no extra LDS round trip is exposed: 26-32 vector instructions per batch instead of 40)
-        // -- is parity-green and 6 % SLOWER alone, 4 % beside the front stage: an LDS instruction occupies the CU's LDS pipe
-        // for 4.2-5 cycles whatever its width and however many lanes share an address (tools/ubench_lds_broadcast.hip), the
-        // eight slab reads of a batch already keep it busy 35 of the batch's ~50 cycles, and four more reads per batch cost
-        // more than 14 fewer vector instructions save.  profiles/r4_wide_ablation.txt, section E.  Also measured and gone:
-        // half batches for the tails (neutral), a run-time batch loop (12 KB of code instead of 20: 3.2 -> 3.6 ms alone).
-#define GWBP_BATCH(B0)                                                                                                \
-    {                                                                                                                 \
-        u32 px_[kB];                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                \
-            px_[j] = (kAbl & 32) && j ? px_[0] + (u32)j : readlane_u(ev.pix, (int)((B0) + j));                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                            \
-        _Pragma("unroll") for (int j = 0; j < kB; ++j) f[j] = lds_read_b128((px_[j] << 10) + row_base);               \
-        __builtin_amdgcn_sched_barrier(0);                                                                            \
-        float w_[kB];                                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                \
-            w_[j] = (kAbl & 32) && j ? w_[0] : readlane_f(ev.w, (int)((B0) + j));                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                            \
-        _Pragma("unroll") for (int j = 0; j < kB; ++j)                                                                \
-        {                                                                                                             \
-            acc_lo = pk_fma(w_[j], f[j].xy, acc_lo);                                                                  \
-            acc_hi = pk_fma(w_[j], f[j].zw, acc_hi);                                                                  \
-        }                                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                            \
-    }
-#pragma unroll
-        for (int B = 0; B < 64 / kB; ++B) {
-            if ((u32)kB * B >= n)
-                break;
-            GWBP_BATCH(kB * B)
-            if (B == 0)
-                after_first();
-        }
-#undef GWBP_BATCH
-    };
 
-    // Visit pipeline.  `cur` is processed, the entries of `nxt` are in flight into the landing buffer (loaded at the top of
-    // the previous visit), the descriptor of the visit after `nxt` is read from the table during this visit, its index
-    // claimed at the top of it.
+    // Visit pipeline.  `cur` is processed, the carry dwords of `nxt` (and the L2 warm-up of its entries) are in flight into the
+    // landing buffer (issued at the top of this visit), the descriptor of the visit after `nxt` is read from the table during
+    // this visit, its index claimed at the top of it.  The entry stream runs one batch ahead: when a visit starts, its first
+    // batch sits in the SGPR tuple of parity `par_s`; its last batch fetches the first batch of `nxt`.
     auto visits = [&](auto bottom) __attribute__((always_inline)) -> bool {
-        Land L = {{{0.f, 0u}, {0.f, 0u}}, {0.f, 0.f, 0.f, 0.f}};
+        Land L = {0u, {0.f, 0.f, 0.f, 0.f}};
         u32 cl = 0;
         u32x3_t tn = {0u, 0u, 0u};
         claim_issue(cl, claim_addr, lane);
@@ -575,6 +558,9 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
             u32 h_nxt = uniform(cl);
             Visit nxt = decode(table[slot_of(min(h_nxt, nv - 1u))]);
             wait_land<0>(L); // (one exposed L2 round trip per wave and pass; the steady-state wait below then holds from the start)
+            u32 par_s = 0; // which tuple holds the batch about to run
+            if (!(kAbl & 2))
+                batch_prime<0>(entries_of(cur));
             for (;;) {
                 const bool vnxt = h_nxt < nv;
                 claim_issue(cl, claim_addr, lane); // the visit after nxt
@@ -583,14 +569,6 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
 #ifdef GWBP_STAMPS
                 ++n_vis_prof;
 #endif
-                // consume the landing buffer: lanes past the visit's entries (clamp-free loads: the next record's
-                // entries, or the other half's) get w = 0 and a pixel that reads 0 -- 0 x inf at a real pixel is NaN
-                EV ev0, ev1;
-                {
-                    const bool in0 = (u32)lane < cur.n, in1 = (u32)(lane + 64) < cur.n;
-                    ev0.w = in0 ? L.e[0].w : 0.f, ev0.pix = in0 ? L.e[0].pix : kNoPix;
-                    ev1.w = in1 ? L.e[1].w : 0.f, ev1.pix = in1 ? L.e[1].pix : kNoPix;
-                }
                 const bool resume = decltype(bottom)::value && cur.span;
                 acc_lo = resume ? f32x2_t{L.c[0], L.c[1]} : f32x2_t{0.f, 0.f};
                 acc_hi = resume ? f32x2_t{L.c[2], L.c[3]} : f32x2_t{0.f, 0.f};
@@ -598,26 +576,36 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
                 // the loads fresh registers and reconciles the names with v_mov copies on the loop's back edge -- copies of
                 // registers whose data has not arrived yet (found as a wide-vs-narrow mismatch at C2 size only).  This empty
                 // volatile asm pins the selects above in front of the (volatile) loads.
-                asm volatile("" : "+v"(ev0.w), "+v"(ev0.pix), "+v"(ev1.w), "+v"(ev1.pix), "+v"(acc_lo), "+v"(acc_hi));
+                asm volatile("" : "+v"(acc_lo), "+v"(acc_hi));
                 // unconditional (nxt is a valid record even when its claim came too late: harmless loads, drained after the
                 // loop); nothing but this visit's flush follows before the next visit's wait
                 prefetch(nxt, L, bottom);
                 u32 h_n2 = nv;
-                bool have_n2 = false;
-                auto after_first = [&]() __attribute__((always_inline)) {
-                    // the claim has returned with the first batch (LDS operations complete in order): read its descriptor
+                if (!(kAbl & 2)) {
+                    // ceil(n / 8) batches; the run behind the last one is the next visit's first batch (no next visit: this
+                    // visit's own first batch once more -- a valid address, never consumed)
+                    const u64 e_cur = entries_of(cur), e_nxt = entries_of(vnxt ? nxt : cur);
+                    const u32 nb = (cur.n + 7u) >> 3;
+#pragma unroll 1
+                    for (u32 b = 0;;) {
+                        const u64 next = (b + 1u < nb) ? e_cur + (u64)((b + 1u) << 6) : e_nxt;
+                        batch_run(par_s, next, row_base, acc_lo, acc_hi);
+                        par_s ^= 1u;
+                        if (b == 0) {
+                            // the claim has returned with the first batch (its last FMA waited for lgkmcnt(0)): read its descriptor,
+                            // which lands under the second batch -- or is waited for below
+                            wait_lds(cl);
+                            h_n2 = uniform(cl);
+                            table_issue(tn, kTabOff + 16u * slot_of(min(h_n2, nv - 1u)));
+                        }
+                        if (++b == nb)
+                            break;
+                    }
+                } else {
                     wait_lds(cl);
                     h_n2 = uniform(cl);
                     table_issue(tn, kTabOff + 16u * slot_of(min(h_n2, nv - 1u)));
-                    have_n2 = true;
-                };
-                if (!(kAbl & 2)) {
-                    run_vec(ev0, min(64u, cur.n), after_first);
-                    if (cur.n > 64u)
-                        run_vec(ev1, cur.n - 64u, []() {});
                 }
-                if (!have_n2)
-                    after_first();
                 // exactly kFlush VMEM operations
                 if (!decltype(bottom)::value && cur.span) { // park the partial sums: plain stores, same shape as the atomics
                     const u64 cr = sbase(carry + ((u64)((kAbl & 16) ? 0u : cur.row) << 10));
@@ -648,7 +636,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_wide(
                         store_c<768>(lane4, acc_hi.y, cr);
                     }
                 }
-                wait_lds(tn); // (issued at least one batch ago)
+                wait_lds(tn); // (issued a batch ago unless the visit had only one)
                 if (!vnxt)
                     break;
                 cur = nxt;

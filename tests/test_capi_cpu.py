@@ -126,10 +126,15 @@ def test_inline_asm_vmem_bases_come_from_the_scalar_alu(tmp_path):
                               stderr=subprocess.DEVNULL)
         assert check_asm_hazards.scan(str(out)) == []
         if name == "scatter_wide":
+            # round 5: the entry stream lives in two fixed SGPR tuples (s[68:83], s[84:99]) ACROSS inline-asm statements, which is
+            # only sound while hipcc never allocates them (amdgpu_num_sgpr(76)); the kernel descriptor must still cover them
+            assert check_asm_hazards.reserved_sgpr_uses(str(out)) == []
+            assert "s_load_dwordx16 s[68:68+15]" in out.read_text() and "s_load_dwordx16 s[84:84+15]" in out.read_text()
+            assert set(re.findall(r"\.amdhsa_next_free_sgpr (\d+)", out.read_text())) == {"100"}
             # The 256-channel kernel's register ALLOCATION decides how many front-stage waves fit beside it on a SIMD, and the
             # step time with it (scatter_wide.hip, "REGISTER BUDGET": 104 allocated = one 64-register front wave per SIMD is
-            # the measured optimum; 120 shuts the front stage out until the kernel ends).  Both instantiations must ask for
-            # 97..104 registers.
+            # the measured optimum; 120 shuts the front stage out until the kernel ends).  The full-resolution instantiation must ask
+            # for 97..104 registers, the bilinear one (its staging loop holds 16 texel loads) for at most 112.
             txt = out.read_text()
-            found = re.findall(r"k_scatter_wideILb([01])E\S*\.num_vgpr, (\d+)", txt)
-            assert len(found) == 2 and all(97 <= int(n) <= 104 for _, n in found), found
+            found = dict(re.findall(r"k_scatter_wideILb([01])E\S*\.num_vgpr, (\d+)", txt))
+            assert len(found) == 2 and 97 <= int(found["0"]) <= 104 and 97 <= int(found["1"]) <= 112, found

@@ -28,6 +28,36 @@ def scan(path):
     return bad
 
 
+def reserved_sgpr_uses(path, lo=68, hi=99):
+    """k_scatter_wide keeps its scalar entry stream in two FIXED SGPR tuples, s[68:83] and s[84:99], across inline-asm statements;
+    the kernel is compiled with amdgpu_num_sgpr(76) so that hipcc itself stays inside s0..s67.  Returns every compiler-emitted
+    instruction (outside ;;#ASMSTART .. ;;#ASMEND) of a k_scatter_wide body that names a register of that range."""
+    bad, in_asm, in_kernel = [], False, False
+    for raw in open(path):
+        l = raw.strip()
+        if l.endswith(":") or " ; @" in l:
+            if re.match(r"_ZN\S*k_scatter_wide\S*:", l):
+                in_kernel = True
+            continue
+        if l.startswith(".Lfunc_end"):
+            in_kernel = False
+        if l.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if l.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not in_kernel or in_asm or not l or l[0] in ";.":
+            continue
+        code = l.split(";")[0]
+        for m in re.finditer(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]", code):
+            a, b = (int(m.group(1)),) * 2 if m.group(1) else (int(m.group(2)), int(m.group(3)))
+            if a <= hi and b >= lo:
+                bad.append(l)
+                break
+    return bad
+
+
 if __name__ == "__main__":
     total = 0
     for f in sys.argv[1:]:
@@ -35,5 +65,9 @@ if __name__ == "__main__":
         for p, l in b:
             print(f"{f}: HAZARD {p}  ->  {l}")
         total += len(b)
+        r = reserved_sgpr_uses(f)
+        for l in r:
+            print(f"{f}: RESERVED SGPR outside inline asm: {l}")
+        total += len(r)
     print("hazards:", total)
     sys.exit(1 if total else 0)
