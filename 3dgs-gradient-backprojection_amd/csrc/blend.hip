@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         T[q] = (ix < V.W && iy < V.H) ? 1.0f : 0.0f;
         Tout[q] = 1.0f;
     }
-    u32 page_pos = 0, page_left = 0, npairs = 0, hdr_n = 0; // wave-uniform
+    u32 page_pos = 0, page_left = 0, npairs = 0, hdr_n = 0, span_n = 0; // wave-uniform
     bool dead = false;                                     // wave-uniform: pool exhausted
 
     // kFused: the lane's four pixels, kFusedCh channels each, stay in registers for the whole tile (pixels outside the
@@ -413,7 +413,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     h.woff[0] = page_pos, h.woff[1] = page_pos + base[1];
                     h.woff[2] = page_pos + base[2], h.woff[3] = page_pos + base[3];
                     h.counts = cnt[0] | (cnt[1] << 8) | (cnt[2] << 16) | (cnt[3] << 24);
-                    h.wsum = (u32)__float_as_int(wsum), h.pad = 0;
+                    // kHalves: a record with entries in BOTH halves of the tile gets the next carry row of its tile (k_scatter_wide
+                    // parks its partial sums there between the two half-tile passes): compact indices keep a workgroup's carry
+                    // rows few and hot in L2
+                    const bool spans = WSUM && (cnt[0] + cnt[1]) != 0 && (cnt[2] + cnt[3]) != 0;
+                    h.wsum = (u32)__float_as_int(wsum), h.carry_row = spans ? span_n : 0xFFFFFFFFu;
                     h.mask[0] = m[0], h.mask[1] = m[1], h.mask[2] = m[2], h.mask[3] = m[3];
                     headers[beg + hdr_n] = h;
                     if constexpr (WSUM) { // gwbp_blend_weights_d: the record's share of d[gid] right here (no k_accum_d)
@@ -422,6 +426,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     }
                 }
                 ++hdr_n;
+                if (WSUM && (cnt[0] + cnt[1]) != 0 && (cnt[2] + cnt[3]) != 0)
+                    ++span_n;
             }
             page_pos += padded;
             page_left -= padded;

@@ -58,7 +58,8 @@ struct __attribute__((aligned(64))) Header {
     u32 woff[4];
     u32 counts;
     u32 wsum; // float bits: sum of the record's weights = the record's share of d[gid] (k_accum_d)
-    u32 pad;
+    u32 carry_row; // k_blend<kHalves>: the record's rank among its tile's records that have entries in both halves (its carry row
+                   // in k_scatter_wide), 0xFFFFFFFF for a record that lies in one half; unused otherwise
     u64 mask[4];
 };
 static_assert(sizeof(Header) == 64, "header is one 64-B line");

@@ -110,7 +110,7 @@ struct Visit { // wave-uniform description of one (record, half) visit
     u32 off;  // first entry
     u32 n;    // entries (1..128)
     u32 span; // nonzero: the record has entries in both halves and owns carry row `row`
-    u32 row;  // the record's index in its tile's header list
+    u32 row;  // the record's carry row: its rank among its tile's records that have entries in both halves
 };
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -325,8 +325,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
     };
     auto tile_of = [&](u32 it) __attribute__((always_inline)) -> u32 { return (it / (u32)n_chunks) * 8u + xcls; };
     // registers that carry a round's loads across the end-of-round barrier
-    uint4 h0 = make_uint4(0u, 0u, 0u, 0u);
-    uint2 h1 = make_uint2(0u, 0u);
+    uint4 h0 = make_uint4(0u, 0u, 0u, 0u), h1 = make_uint4(0u, 0u, 0u, 0u);
     constexpr int kUnits = kHalfPix / (kThreads / 64); // 8 pixels per wave
     // ONE 32-register buffer serves as the landing area of the next slab's loads (from the end of a round to the commit at the
     // top of the next) AND as the batch buffer of the visit loop in between: declared separately, hipcc gave them 32 registers
@@ -340,10 +339,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
     auto stage_issue = [&]() __attribute__((always_inline)) {
         // (a) this round's records
         const u32 rec = rbase + threadIdx.x;
-        h0 = make_uint4(0u, 0u, 0u, 0u), h1 = make_uint2(0u, 0u);
+        h0 = make_uint4(0u, 0u, 0u, 0u), h1 = make_uint4(0u, 0u, 0u, 0u);
         if (threadIdx.x < (u32)kVisCap && rec < n_rec) {
-            h0 = *reinterpret_cast<const uint4 *>(hbase + rec);   // gid, woff[0..2]
-            h1 = reinterpret_cast<const uint2 *>(hbase + rec)[2]; // woff[3], counts
+            h0 = reinterpret_cast<const uint4 *>(hbase + rec)[0]; // gid, woff[0..2]
+            h1 = reinterpret_cast<const uint4 *>(hbase + rec)[1]; // woff[3], counts, wsum, carry row
         }
         // (b) 128 px x 256 ch (first round of a pass only; a second round reuses the slab): wave v stages tile column v of the
         // eight tile rows of this half, one pixel = 4 coalesced dword loads (one per 64-channel group) + one ds_write_b128 per
@@ -361,7 +360,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
 #pragma unroll
             for (int u = 0; u < kUnits; ++u) {
                 const float *src = rows[u] + lane;
-                fbuf[u] = f32x4_t{src[0], src[64], src[128], src[192]};
+                fbuf[u] = f32x4_t{__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + 64), __builtin_nontemporal_load(src + 128),
+                                   __builtin_nontemporal_load(src + 192)};
             }
         } else {
             // No slab for the next round: say so.  Without this the buffer's OLD contents count as live from one round's end to
@@ -429,7 +429,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
         const u32 cnt = h1.y;
         const u32 ct = (cnt & 0xFFu) + ((cnt >> 8) & 0xFFu), cb = ((cnt >> 16) & 0xFFu) + (cnt >> 24);
         const u32 n = phase ? cb : ct;
-        const u32 span = (ct != 0 && cb != 0 && rec < (u32)kCarryRows) ? 0x100u : 0u;
+        // a record in both halves owns carry row h1.w (its rank among the tile's spanning records, from the blend: the rows a
+        // workgroup touches are few and the same for every item, i.e. hot in L2; indexed by the record itself they were twice
+        // as many); a tile with more than kCarryRows of them flushes the rest per half
+        const u32 crow = h1.w;
+        const u32 span = (ct != 0 && cb != 0 && crow < (u32)kCarryRows) ? 0x100u : 0u;
         const bool valid = has && n != 0;
         const u64 m = __ballot(valid);
         if (m != 0ull) { // wave-uniform
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
                     const bool back = valid && n <= (u32)kShortN && mbcnt(ms) < take;
                     mback = __ballot(back);
                     if (back)
-                        table[(u32)kVisCap - 1u - (sbase_ + mbcnt(ms))] = make_uint4(h0.x, phase ? h0.w : h0.y, n | span | (rec << 16), 0u);
+                        table[(u32)kVisCap - 1u - (sbase_ + mbcnt(ms))] = make_uint4(h0.x, phase ? h0.w : h0.y, n | span | (crow << 16), 0u);
                 }
             }
             const u64 mf = m & ~mback;
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
                     wbase = atomicAdd(&ctl[2u + par], (u32)__popcll(mf));
                 wbase = uniform(wbase);
                 if ((mf >> lane) & 1ull)
-                    table[wbase + mbcnt(mf)] = make_uint4(h0.x, phase ? h0.w : h0.y, n | span | (rec << 16), 0u);
+                    table[wbase + mbcnt(mf)] = make_uint4(h0.x, phase ? h0.w : h0.y, n | span | (crow << 16), 0u);
             }
         }
     }
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
         Visit r;
         r.gid = uniform(t.x);
         r.off = uniform(t.y);
-        const u32 ns = uniform(t.z); // entries | spans both halves << 8 | record index (= carry row) << 16
+        const u32 ns = uniform(t.z); // entries | spans both halves << 8 | carry row << 16
         r.n = ns & 0xFFu;
         r.span = ns & 0x100u;
         r.row = ns >> 16;
