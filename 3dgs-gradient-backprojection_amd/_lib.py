@@ -13,6 +13,27 @@ from typing import Optional
 
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
+# The view pipeline (backproject.ViewPipeline) runs the front stages of the next views on side streams beside the scatter kernel
+# of the current one; that only overlaps if the streams sit on DIFFERENT hardware queues.  The HIP runtime creates 4 by default
+# (RCCL takes some of them) and reads GPU_MAX_HW_QUEUES once, when it starts: ask for 8 here, at package import -- which is
+# before the first HIP call in every entry point of this repository (bench.py, run_backproject.py, the tests) -- unless the
+# caller has chosen a value.  If the runtime was already up when the package was imported the setting comes too late;
+# hw_queues_ok() then says so and ViewPipeline refuses to pretend (a pipeline whose streams share a queue runs front + scatter
+# back to back: 5.06 instead of 4.27 ms/view at C2 when this was found).
+HW_QUEUES_WANTED = 8
+_QUEUES_LATE = "GPU_MAX_HW_QUEUES" not in os.environ and torch.cuda.is_initialized()
+os.environ.setdefault("GPU_MAX_HW_QUEUES", str(HW_QUEUES_WANTED))
+
+
+def hw_queues_ok() -> bool:
+    """False when the pipeline's streams may be sharing hardware queues: the HIP runtime started before this package could ask
+    for HW_QUEUES_WANTED queues, or the caller asked for fewer."""
+    try:
+        return not _QUEUES_LATE and int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) >= HW_QUEUES_WANTED
+    except ValueError:
+        return False
+
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgwbp.so")
 CSRC = os.path.join(_HERE, "csrc")
@@ -99,22 +120,34 @@ ARGTYPES = {
 }
 
 _lib: Optional[C.CDLL] = None
+_lib_path = LIB_PATH
+_allow_profile = False
+
+
+def use_library(path: str, allow_profile: bool = False) -> None:
+    """DEVELOPER entry point (tools/, `bench.py --lib`): bind the package to another build of the same C ABI -- an A/B build or
+    a PROFILE / ablation build under tools/lib/ -- instead of the in-tree libgwbp.so.  Must be called before the first
+    operator.  The product path never looks at the environment for this: nothing but an explicit call can swap the library,
+    and a PROFILE build (ablation knobs, possibly invalid results) additionally needs allow_profile=True."""
+    global _lib_path, _allow_profile
+    if _lib is not None:
+        raise GwbpError("use_library() must be called before the library is first used")
+    _lib_path, _allow_profile = os.path.abspath(path), bool(allow_profile)
 
 
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        path = os.environ.get("GWBP_LIB", LIB_PATH)  # GWBP_LIB: developer knob for A/B builds of the same ABI (PROFILE builds
-        # additionally need GWBP_ALLOW_PROFILE=1, see below)
+        path = _lib_path
         if not os.path.exists(path):
             raise GwbpError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU or PyTorch fallback for this path)")
         L = C.CDLL(path)
         L.gwbp_version.restype = C.c_char_p
-        if b"PROFILE" in L.gwbp_version() and os.environ.get("GWBP_ALLOW_PROFILE") != "1":
+        if b"PROFILE" in L.gwbp_version() and not _allow_profile:
             # a PROFILE build reads ablation knobs from the environment and may produce invalid results: never by accident
-            raise GwbpError(f"{path} is a PROFILE build ({L.gwbp_version().decode()}); it is only loaded with "
-                            "GWBP_ALLOW_PROFILE=1 (tools/ablate_scatter.sh, tools/stamp_scatter.py)")
+            raise GwbpError(f"{path} is a PROFILE build ({L.gwbp_version().decode()}); it is only loaded through "
+                            "use_library(path, allow_profile=True) (bench.py --lib, tools/stamp_scatter.py)")
         L.gwbp_last_error_string.restype = C.c_char_p
         for name in EXPORTS[2:]:
             if path != LIB_PATH and not hasattr(L, name):

@@ -129,6 +129,15 @@ class ViewPipeline:
                  allow_wide: bool = True, scatter_workgroups: Optional[int] = None, side_priority: int = -1,
                  front_priority: Optional[bool] = None, fuse_small: bool = True, side_streams: Optional[int] = None):
         self.dev = torch.device(device)
+        from . import _lib
+        if not _lib.hw_queues_ok():
+            # the schedule below is built on streams that run CONCURRENTLY; with the HIP runtime's default of 4 hardware queues
+            # (fewer once RCCL has taken its own) the side streams share a queue with the caller's and the step becomes front +
+            # scatter.  The package asks for 8 when it is imported (_lib.py), which only works before the first HIP call.
+            raise _lib.GwbpError(
+                "ViewPipeline needs GPU_MAX_HW_QUEUES >= %d, read by the HIP runtime when it starts: import gsbp_amd (or set "
+                "the variable) before the first CUDA/HIP call of the process, or run the views with pipeline=False"
+                % _lib.HW_QUEUES_WANTED)
         self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev, tight_binning=True)
                                                   for _ in range(2)]
         # Scatter grid under overlap: one persistent workgroup per CU is the measured optimum once the front stage is

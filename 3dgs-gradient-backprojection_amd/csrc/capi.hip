@@ -134,7 +134,9 @@ int make_layout(const gwbp_caps *c, Layout *L)
     L->hdr_count = take((size_t)L->max_tiles * sizeof(u32));
     L->headers = take((size_t)L->isect_cap * sizeof(Header));
     L->carry = take((size_t)kCarryWgs * kCarryRows * 256 * sizeof(float));
-    L->wpool = take((size_t)L->pair_cap * sizeof(WPair) + 1024); // + 128 entries: k_scatter_wide loads 128 entries per visit
+    // + 128 entries of slack behind the pool: k_scatter_wide's L2 warm-up touches one dword per 128-B line of a visit's run and
+    // may reach one line past its end; its scalar batch loads stay inside the record's padded lists
+    L->wpool = take((size_t)L->pair_cap * sizeof(WPair) + 1024);
                                                                   // without clamping to the visit's length
     L->total = o;
     return GWBP_OK;

@@ -17,6 +17,7 @@ import torch
 
 from .engine import Engine
 from .rasterization import rasterization
+from .synthetic import view_shard
 
 _PER_GAUSSIAN = ("means", "features_dc", "features_rest", "scaling", "rotation", "opacity", "features")
 
@@ -26,9 +27,21 @@ def _activated(splats: Dict[str, torch.Tensor]):
     return (splats["means"], splats["rotation"], torch.exp(splats["scaling"]), torch.sigmoid(splats["opacity"]))
 
 
+def _group():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
 def gradient_mask(splats: Dict[str, torch.Tensor], viewmats: torch.Tensor, K: torch.Tensor, width: int,
                   height: int) -> torch.Tensor:
-    """bool[N]: Gaussians that receive weight in at least one of the views (utils.py:236-257)."""
+    """bool[N]: Gaussians that receive weight in at least one of the views (utils.py:236-257).
+
+    Under a process group the views are sharded r, r + R, ... like the field build and the per-rank weight sums are
+    all-reduced: every rank returns the SAME mask (an all-reduce hands every rank the same bits), so the Gaussian slices and
+    the shapes of the collectives that follow agree by construction."""
+    dist, rank, world = _group()
     means, quats, scales, opac = _activated(splats)
     n, dev = means.shape[0], means.device
     width, height = int(width), int(height)  # utils.py:247-248 passes 0-d tensors
@@ -36,7 +49,7 @@ def gradient_mask(splats: Dict[str, torch.Tensor], viewmats: torch.Tensor, K: to
     eng.set_narrow_scatter(False)  # the blend then leaves every record's weight sum in its header
     d = torch.zeros(n, device=dev)
     vm_host, K_host = viewmats.detach().cpu(), K.detach().cpu()
-    for v in range(viewmats.shape[0]):
+    for v in view_shard(viewmats.shape[0], rank, world):
         view = eng.view(vm_host[v], K_host, width, height)
         while True:
             eng.project(view, means, quats, scales, opac)
@@ -47,6 +60,8 @@ def gradient_mask(splats: Dict[str, torch.Tensor], viewmats: torch.Tensor, K: to
                 break
             eng.grow(st)
         eng.accumulate_d(view, d)  # after the overflow check: a retried view must not be counted twice
+    if dist is not None:
+        dist.all_reduce(d, op=dist.ReduceOp.SUM)
     return d > 0
 
 
@@ -65,14 +80,17 @@ def prune_by_gradients(splats: Dict[str, torch.Tensor], viewmats: torch.Tensor, 
 def check_proper_pruning(splats: Dict[str, torch.Tensor], pruned: Dict[str, torch.Tensor], viewmats: torch.Tensor,
                          K: torch.Tensor, width: int, height: int) -> Dict[str, float]:
     """utils.test_proper_pruning (utils.py:292-360): SH-degree-3 render of every view before and after pruning through
-    the drop-in rasterization(); asserts max |difference| < 1 / (255 * 2) like utils.py:353-355."""
+    the drop-in rasterization(); asserts max |difference| < 1 / (255 * 2) like utils.py:353-355.  Under a process group each rank
+    renders its shard of the views; the maximum and the total are reduced, every rank asserts on the same numbers."""
+    dist, rank, world = _group()
+
     def cols(s):
         return torch.cat([s["features_dc"], s["features_rest"]], dim=1)
 
     a, b = _activated(splats), _activated(pruned)
     total, worst = 0.0, 0.0
     with torch.no_grad():
-        for v in range(viewmats.shape[0]):
+        for v in view_shard(viewmats.shape[0], rank, world):
             kw = dict(viewmats=viewmats[v][None], Ks=K[None], sh_degree=3, width=int(width), height=int(height),
                       want_meta=False)
             out, _, _ = rasterization(*a, cols(splats), **kw)
@@ -80,6 +98,11 @@ def check_proper_pruning(splats: Dict[str, torch.Tensor], pruned: Dict[str, torc
             diff = (out - out_p).abs()
             total += float(diff.sum())
             worst = max(worst, float(diff.max()))
+    if dist is not None:
+        t = torch.tensor([worst, total], dtype=torch.float64, device=viewmats.device)
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        worst, total = float(t[0]), float(t[1])
     n0, n1 = splats["means"].shape[0], pruned["means"].shape[0]
     assert worst < 1 / (255 * 2), "Max pixel error should be less than 1/(255*2), safety margin"
     return {"percentage_pruned": 100.0 * (n0 - n1) / max(n0, 1), "max_pixel_error": worst, "total_pixel_error": total}

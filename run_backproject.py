@@ -33,18 +33,27 @@ def main():
     ap.add_argument("--no-prune", action="store_true",
                     help="skip the pruning step and build the field on ALL Gaussians (the default, like the reference's main(), "
                          "is prune_by_gradients -> test_proper_pruning -> build on the pruned scene, backproject.py:320-325)")
+    ap.add_argument("--prune-by-product", action="store_true",
+                    help="ONE sweep instead of two: build the field on all Gaussians and take the mask from the same "
+                         "denominators (keep = d > 0), then drop the pruned rows.  Not the reference's arithmetic to the last "
+                         "digit: a pruned Gaussian has no weight anywhere but may be the one that TERMINATES pixels "
+                         "(T' <= 1e-4), so building with it present moves a few kept rows (C1: median 0, 99 % of the rows "
+                         "within 2e-3 of the prune-first result, tests/test_gpu_cli.py)")
+    ap.add_argument("--dist-backend", default="nccl", help="process-group backend under torchrun (nccl = RCCL over xGMI)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="every rank uses cuda:0 (with --dist-backend gloo: the N > 1 bookkeeping on a one-GPU box)")
     args = ap.parse_args()
 
+    import gsbp_amd  # BEFORE the first HIP call: the package asks the runtime for the hardware queues its view pipeline needs
     if not torch.cuda.is_available():
         raise RuntimeError("a HIP device is required (the reference likewise requires CUDA, backproject.py:314)")
     import torch.distributed as dist
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(args.dist_backend)
     dev = torch.device("cuda", torch.cuda.current_device())
     rank = dist.get_rank() if dist.is_initialized() else 0
 
-    import gsbp_amd
     from gsbp_amd import scene_io, synthetic as syn
 
     if args.synthetic:
@@ -79,35 +88,41 @@ def main():
 
     # backproject.py:323-325: splats_optimized = prune_by_gradients(splats); test_proper_pruning(splats, splats_optimized);
     # the field is then built on the PRUNED scene.  The mask costs one blend per view (no scatter).  Under a process group
-    # rank 0 computes it and BROADCASTS it: every rank then slices its Gaussians with the same bits, so the shapes of the
-    # collectives that follow agree by construction (a mask recomputed per rank could differ in a bit -- float atomics -- and
-    # hang the reduce-scatter).
+    # the sweep AND the render check are sharded over the ranks by view like the field build itself (round 4 had rank 0 do
+    # both alone while the others waited: ~0.3 s at C2 against a 0.09 s field build per rank at 8 GPUs); the weight sums are
+    # all-reduced, so every rank holds the SAME mask and the shapes of the collectives that follow agree by construction.
     n_all = means.shape[0]
     keep = None
-    if not args.no_prune:
-        vm_dev, K_dev = viewmats.to(dev), K.to(dev)
-        if rank == 0:
-            keep = gsbp_amd.pruning.gradient_mask(splats, vm_dev, K_dev, W, H)
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            mask_u8 = keep.to(torch.uint8) if rank == 0 else torch.empty(n_all, dtype=torch.uint8, device=dev)
-            dist.broadcast(mask_u8, src=0)
-            keep = mask_u8.bool()
+    vm_dev, K_dev = viewmats.to(dev), K.to(dev)
+
+    def report_and_check(keep):
         if rank == 0:
             print("Total splats", keep.numel())  # utils.py:258-260
             print("Pruned", int((~keep).sum()), "splats")
             print("Remaining", int(keep.sum()), "splats")
-        if "features_dc" in splats and rank == 0:  # utils.test_proper_pruning renders with the SH colours (checkpoints only)
+        if "features_dc" in splats:  # utils.test_proper_pruning renders with the SH colours (checkpoints only)
             pruned = {k: (v[keep] if k in gsbp_amd.pruning._PER_GAUSSIAN else v) for k, v in splats.items()}
             rep = gsbp_amd.check_proper_pruning(splats, pruned, vm_dev, K_dev, W, H)
-            print("Percentage pruned: ", rep["percentage_pruned"])  # utils.py:348-359
-            print("Max pixel error: ", rep["max_pixel_error"])
-            print("Total pixel error: ", rep["total_pixel_error"])
+            if rank == 0:
+                print("Percentage pruned: ", rep["percentage_pruned"])  # utils.py:348-359
+                print("Max pixel error: ", rep["max_pixel_error"])
+                print("Total pixel error: ", rep["total_pixel_error"])
+
+    if not args.no_prune and not args.prune_by_product:
+        keep = gsbp_amd.pruning.gradient_mask(splats, vm_dev, K_dev, W, H)
+        report_and_check(keep)
         means, quats, scales, opac = means[keep], quats[keep], scales[keep], opac[keep]
 
     reduction = "mean" if args.feature == "dino" else "sum"  # backproject.py:263,283 vs :127,145
     out, F, d, stats = gsbp_amd.create_feature_field(means, quats, scales, opac, viewmats, K, W, H, feature_fn, dim,
                                                      reduction=reduction, encoder=encoder, return_partials=True,
                                                      verbose=True)
+    if args.prune_by_product and not args.no_prune:
+        # "the mask comes free from the fused kernel" -- d is the all-reduced denominator of every Gaussian,
+        # identical on every rank
+        keep = d > 0
+        report_and_check(keep)
+        out = out[keep]
     if rank == 0:
         name = "features_lseg_compressed.pt" if encoder is not None else f"features_{args.feature}.pt"
         print("saved", scene_io.save_features(out.cpu(), args.results_dir, name), tuple(out.shape),

@@ -89,16 +89,21 @@ def test_product_package_never_imports_the_oracle():
 
 def test_profile_build_is_refused_without_explicit_opt_in(tmp_path, monkeypatch):
     """A library whose gwbp_version() says PROFILE (ablation knobs read from the environment, results may be invalid)
-    must not be picked up through a stray GWBP_LIB: _lib.lib() refuses it unless GWBP_ALLOW_PROFILE=1."""
+    is only ever loaded through an explicit _lib.use_library(path, allow_profile=True); the environment cannot swap the
+    product library at all (GWBP_LIB was a developer knob in the product path)."""
     import subprocess
     src = tmp_path / "fake.c"
     src.write_text('const char *gwbp_version(void) { return "libgwbp gfx950 (PROFILE build)"; }\n'
                    'const char *gwbp_last_error_string(void) { return ""; }\n')
     so = tmp_path / "libfake_profile.so"
     subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
-    monkeypatch.setenv("GWBP_LIB", str(so))
-    monkeypatch.delenv("GWBP_ALLOW_PROFILE", raising=False)
     monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("GWBP_LIB", str(so))          # ignored: the package binds to its own in-tree library
+    monkeypatch.setenv("GWBP_ALLOW_PROFILE", "1")
+    assert _lib._lib_path == _lib.LIB_PATH
+    monkeypatch.setattr(_lib, "_lib_path", _lib.LIB_PATH)
+    monkeypatch.setattr(_lib, "_allow_profile", False)
+    _lib.use_library(str(so))                          # explicit, but without the PROFILE opt-in: refused
     with pytest.raises(_lib.GwbpError, match="PROFILE"):
         _lib.lib()
     assert _lib._lib is None

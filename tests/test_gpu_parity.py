@@ -515,30 +515,35 @@ def test_pipelined_driver_equals_serial_driver(dev):
     assert rel_row_err(res[0][0], res[1][0]) <= 1e-5 and np.abs(res[0][1] - res[1][1]).max() <= 1e-4 * res[1][1].max()
 
 
-@pytest.mark.parametrize("fname,cfgname", [("gsplat_g0.npz", None), ("gsplat_t1.npz", "T1")])
-def test_hip_against_gsplat_capture(dev, fname, cfgname):
+def _capture_cases():
+    from util import capture_tool
+    return capture_tool().CASES
+
+
+@pytest.mark.parametrize("fname,cfgname,dim,enc_dim", _capture_cases(), ids=[c[0] for c in _capture_cases()])
+def test_hip_against_gsplat_capture(dev, fname, cfgname, dim, enc_dim):
     """The HIP path against a capture of REAL gsplat 1.4.0 output (tools/capture_gsplat_fixture.py), when one has been
-    committed; skipped otherwise (parity unpinned).  Same bar as tests/test_oracle.py::test_oracle_against_gsplat_capture:
+    committed; skipped otherwise (parity unpinned).  One case per kernel family (general / fused small-D / encoder + fused /
+    128-channel / 256-channel scatter).  Same bar as tests/test_oracle.py::test_oracle_against_gsplat_capture:
     99 % of the rows within the north_star 1e-4, at most 0.2 % threshold rows beyond it."""
-    from util import capture_report
+    from util import capture_report, capture_tool
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fname)
     if not os.path.exists(path):
         pytest.skip(f"{fname} not captured yet (needs CUDA + gsplat==1.4.0)")
     cap = dict(np.load(path))
     if cfgname is None:
         g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g0.npz")))
-        W, H, D = 64, 48, 8
-        feats = [torch.from_numpy(f) for f in g["feats"]]
-        t = {k: torch.from_numpy(g[k]).to(dev) for k in ("means", "quats", "scales", "opac", "K", "vms")}
+        W, H = 64, 48
     else:
         cfg = syn.CONFIGS[cfgname]
-        m, q, s, o = syn.activate(syn.make_scene(cfg))
-        t = dict(means=m.to(dev), quats=q.to(dev), scales=s.to(dev), opac=o.to(dev), K=syn.intrinsics(cfg).to(dev),
-                 vms=syn.make_cameras(cfg).to(dev))
-        W, H, D = cfg.width, cfg.height, cfg.feat_dim
-        feats = [syn.make_feature_map(cfg, v) for v in range(cfg.n_views)]
+        g = capture_tool().case_inputs(cfgname, dim, enc_dim)
+        W, H = cfg.width, cfg.height
+    t = {k: torch.from_numpy(np.asarray(g[k])).to(dev) for k in ("means", "quats", "scales", "opac", "K", "vms")}
+    feats = [torch.from_numpy(f) for f in g["feats"]]
+    encoder = torch.from_numpy(g["encoder"]).to(dev) if g.get("encoder") is not None else None
+    D = feats[0].shape[-1]
     out, F, d, st = gsbp_amd.create_feature_field(t["means"], t["quats"], t["scales"], t["opac"], t["vms"], t["K"], W, H,
-                                                   lambda v: feats[v].to(dev), D, return_partials=True)
+                                                   lambda v: feats[v].to(dev), D, encoder=encoder, return_partials=True)
     eng = gsbp_amd.Engine(t["means"].shape[0], W, H, device=dev)
     proj = eng.project(eng.view(t["vms"][0].cpu(), t["K"].cpu(), W, H), t["means"], t["quats"], t["scales"], t["opac"],
                        want_outputs=True)

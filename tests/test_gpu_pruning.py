@@ -42,3 +42,23 @@ def test_proper_pruning_at_c2_size(dev):
     assert 3e5 < kept < cfg.n_gaussians
     rep = gsbp_amd.check_proper_pruning(splats, pruned, vms, K, cfg.width, cfg.height)
     assert rep["max_pixel_error"] < 1 / 510
+
+
+def test_mask_as_a_by_product_of_the_build_at_c2_size(dev):
+    """SURVEY.md 8(f) N1 at C2 size (1M Gaussians, two 1600x1060 views, 16-channel maps to keep it short): the denominators of a
+    field built on ALL Gaussians give the pruning sweep's mask bit for bit, and the kept rows of that field are the field of
+    the pruned scene except where a pruned Gaussian had been terminating pixels (see tests/test_gpu_cli.py)."""
+    cfg = syn.CONFIGS["C2"]
+    splats = _splats(cfg, dev)
+    vms, K = syn.make_cameras(cfg, n_views=2).to(dev), syn.intrinsics(cfg).to(dev)
+    mask = gsbp_amd.gradient_mask(splats, vms, K, cfg.width, cfg.height)
+    g = [splats["means"], splats["rotation"], torch.exp(splats["scaling"]), torch.sigmoid(splats["opacity"])]
+
+    def fn(v):
+        return syn.make_feature_map(cfg, v, device=dev, dim=16)
+
+    out_all, _, d, st = gsbp_amd.create_feature_field(*g, vms, K, cfg.width, cfg.height, fn, 16, return_partials=True)
+    assert st["overflow"] == 0 and torch.equal(d > 0, mask)
+    out_pruned = gsbp_amd.create_feature_field(*[t[mask] for t in g], vms, K, cfg.width, cfg.height, fn, 16)
+    err = (out_all[mask] - out_pruned).abs().max(dim=1).values
+    assert float(err.median()) <= 1e-6 and float(err.quantile(0.99)) <= 2e-3 and float(err.max()) <= 0.2

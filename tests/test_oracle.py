@@ -213,11 +213,13 @@ def test_finalize_matches_reference_lines(orc):
     assert np.abs(gsbp_amd.finalize_reference(gf, torch.from_numpy(d).float()).numpy() - out).max() < 2e-7
 
 
-CAPTURES = [("gsplat_g0.npz", None), ("gsplat_t1.npz", "T1")]
+from util import capture_tool  # noqa: E402
+
+CAPTURES = capture_tool().CASES  # (file, config or None = g0.npz, feature channels, encoder outputs): one per kernel family
 
 
-@pytest.mark.parametrize("fname,cfgname", CAPTURES)
-def test_oracle_against_gsplat_capture(orc, fname, cfgname):
+@pytest.mark.parametrize("fname,cfgname,dim,enc_dim", CAPTURES, ids=[c[0] for c in CAPTURES])
+def test_oracle_against_gsplat_capture(orc, fname, cfgname, dim, enc_dim):
     """PINS THE ORACLE when a capture of real gsplat 1.4.0 output exists (tools/capture_gsplat_fixture.py, run by a
     maintainer with CUDA; only the resulting .npz data is committed).  Without the file the oracle stays PARITY UNPINNED
     and this test is skipped.  Threshold rows (pairs exactly at the alpha >= 1/255 or T' <= 1e-4 cut) are expected over
@@ -230,14 +232,13 @@ def test_oracle_against_gsplat_capture(orc, fname, cfgname):
     cap = dict(np.load(path))
     if cfgname is None:
         g = dict(np.load(GOLD))
-        W, H, D = W0, H0, 8
-        feats = g["feats"]
+        W, H = W0, H0
     else:
         cfg = syn.CONFIGS[cfgname]
-        m, q, s, o = [t.numpy() for t in syn.activate(syn.make_scene(cfg))]
-        g = dict(means=m, quats=q, scales=s, opac=o, K=syn.intrinsics(cfg).numpy(), vms=syn.make_cameras(cfg).numpy())
-        W, H, D = cfg.width, cfg.height, cfg.feat_dim
-        feats = [syn.make_feature_map(cfg, v).numpy() for v in range(cfg.n_views)]
+        g = capture_tool().case_inputs(cfgname, dim, enc_dim)
+        W, H = cfg.width, cfg.height
+    feats = g["feats"] if g.get("encoder") is None else g["feats"] @ g["encoder"]  # backproject_compressed.py:127
+    D = feats.shape[-1]
     out, F, d, _ = orc.backproject_oracle(g["means"], g["quats"], g["scales"], g["opac"], g["vms"], g["K"], W, H,
                                           lambda v: feats[v], D)
     proj = orc.project(g["means"], g["quats"], g["scales"], g["vms"][0], g["K"], W, H)
@@ -296,3 +297,18 @@ def test_capture_script_stays_in_sync_with_its_consumers(orc, gold, tmp_path, mo
         assert rep[k]["max_rel"] == 0.0, (k, rep[k])
     for k in ("v0_alphas", "v0_isect_ids", "v0_flatten_ids", "F_views", "d_views", "gsplat_version"):
         assert k in cap, k
+    # the compressed case (feats @ encoder, then D = 16) and the table the consumers are parametrised over
+    assert [c[0] for c in mod.CASES] == ["gsplat_g0.npz", "gsplat_t1.npz", "gsplat_c1.npz", "gsplat_t1_d64enc16.npz",
+                                         "gsplat_t1_d128.npz", "gsplat_t1_d256.npz"]
+    enc = (np.random.default_rng(3).standard_normal((8, 4)) / 8 ** 0.5).astype(np.float32)
+    path2 = str(tmp_path / "gsplat_enc.npz")
+    mod.capture({**{k: g[k] for k in ("means", "quats", "scales", "opac", "K", "vms", "feats")}, "encoder": enc}, path2,
+                per_view=False)
+    cap2 = dict(np.load(path2))
+    fe = g["feats"] @ enc
+    out2, F2, d2, _ = orc.backproject_oracle(g["means"], g["quats"], g["scales"], g["opac"], g["vms"], g["K"], W0, H0,
+                                             lambda v: fe[v], 4)
+    rep2 = capture_report(cap2, out2, F2, d2)
+    assert cap2["F"].shape == (256, 4) and "F_views" not in cap2 and all(rep2[k]["max"] <= 1e-5 for k in ("F", "d", "out"))
+    t1 = mod.case_inputs("T1", 64, 16)
+    assert t1["feats"].shape[-1] == 64 and t1["encoder"].shape == (64, 16) and t1["means"].shape == (syn.CONFIGS["T1"].n_gaussians, 3)

@@ -93,3 +93,14 @@ def capture_report(cap, out, F, d, radii=None, means2d=None, conics=None, depths
             err = np.abs(theirs[vis].astype(np.float64) - sel[vis]) / np.maximum(np.abs(theirs[vis]), 1e-6)
             rep[name] = {"max_rel": float(err.max()) if err.size else 0.0}
     return rep
+
+
+def capture_tool():
+    """tools/capture_gsplat_fixture.py as a module: its CASES table and case_inputs() are shared with the consumer tests."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "capture_gsplat_fixture.py")
+    spec = importlib.util.spec_from_file_location("capture_gsplat_fixture", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

@@ -2,12 +2,11 @@
 # On the GPU box: A/B of library builds under tools/lib/ (name "product" = the in-tree libgwbp.so), each alone (--serial) and pipelined.
 # usage: tools/ab_libs.sh "product w6 b64" [out dir] [extra bench args]
 out=${2:-gpurun_out/ab}; mkdir -p $out
-export GWBP_ALLOW_PROFILE=1
 for rep in 1 2; do
 for a in $1; do
-  if [ $a = product ]; then unset GWBP_LIB; else export GWBP_LIB=$PWD/tools/lib/libgwbp_$a.so; fi
+  if [ $a = product ]; then LIB=""; else LIB="--lib $PWD/tools/lib/libgwbp_$a.so"; fi
   for sched in --serial ""; do
-    python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-check $3 $sched > $out/${a}${sched}_$rep.json 2>$out/err.txt || tail -3 $out/err.txt
+    python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-check $LIB $3 $sched > $out/${a}${sched}_$rep.json 2>$out/err.txt || tail -3 $out/err.txt
     python - "$a" "$sched" $out/${a}${sched}_$rep.json <<'PY'
 import json,sys
 j=json.load(open(sys.argv[3]))

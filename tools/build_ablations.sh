@@ -1,6 +1,6 @@
 #!/bin/bash
 # Structure-preserving ablation builds of k_scatter_wide (compile-time: the counted waits stay intact).
-# usage: tools/build_ablations.sh "1 2 3 4 9 16"   ->  tools/lib/libgwbp_abl<bits>.so   (load with GWBP_LIB=... GWBP_ALLOW_PROFILE=1)
+# usage: tools/build_ablations.sh "1 2 3 4 9 16"   ->  tools/lib/libgwbp_abl<bits>.so   (load with bench.py --lib <path>, i.e. _lib.use_library(path, allow_profile=True))
 set -e
 cd "$(dirname "$0")/../3dgs-gradient-backprojection_amd/csrc"
 make -s -j8 PROFILE=1

@@ -6,8 +6,13 @@ Cannot run in this project's containers (gsplat is CUDA-only, not vendored, no n
 runs, once:
 
     pip install gsplat==1.4.0 torch numpy
-    python tools/capture_gsplat_fixture.py            # reads tests/golden/g0.npz (+ the seeded T1 scene if this package
-                                                      # is importable), writes tests/golden/gsplat_g0.npz [, gsplat_t1.npz]
+    python tools/capture_gsplat_fixture.py            # reads tests/golden/g0.npz and this package's seeded generators,
+                                                      # writes tests/golden/gsplat_*.npz, one file per entry of CASES below
+
+One run pins every kernel family: g0 / T1 (D = 8 / 24: the general scatter kernel), C1 IN FULL (BASELINE config 1: 10 000
+Gaussians, 4 views 400 x 300, D = 32: the fused blend + scatter kernels), T1 with 64-channel maps through a 64 -> 16 encoder
+(backproject_compressed.py:127: encoder kernel + fused small-D kernel), T1 at D = 128 (k_scatter_full) and at D = 256
+(k_scatter_wide).
 
 and commits the resulting .npz DATA files (inputs are already committed; nothing of gsplat's or the reference's source
 travels).  tests/test_oracle.py::test_oracle_against_gsplat_capture (CPU) and tests/test_gpu_parity.py::
@@ -29,7 +34,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def capture(inp, out_path):
+# (file, seeded config or None = tests/golden/g0.npz, feature channels or None = the config's, encoder outputs or None)
+CASES = [
+    ("gsplat_g0.npz", None, None, None),
+    ("gsplat_t1.npz", "T1", None, None),
+    ("gsplat_c1.npz", "C1", None, None),
+    ("gsplat_t1_d64enc16.npz", "T1", 64, 16),
+    ("gsplat_t1_d128.npz", "T1", 128, None),
+    ("gsplat_t1_d256.npz", "T1", 256, None),
+]
+ENCODER_SEED = 7
+
+
+def case_inputs(cfgname, dim=None, enc_dim=None):
+    """numpy inputs of a capture case (shared with the consumer tests): the seeded scene, cameras and feature maps of this
+    repository's generators (gsbp_amd.synthetic: torch only, no HIP library needed), plus -- compressed variant -- a seeded
+    [dim, enc_dim] encoder N(0, 1) / sqrt(dim) like synthetic.make_encoder."""
+    import torch
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from gsbp_amd import synthetic as syn
+    cfg = syn.CONFIGS[cfgname]
+    means, quats, scales, opac = [x.numpy() for x in syn.activate(syn.make_scene(cfg))]
+    inp = dict(means=means, quats=quats, scales=scales, opac=opac, K=syn.intrinsics(cfg).numpy(),
+               vms=syn.make_cameras(cfg).numpy(),
+               feats=torch.stack([syn.make_feature_map(cfg, v, dim=dim) for v in range(cfg.n_views)]).numpy())
+    if enc_dim:
+        g = torch.Generator(device="cpu").manual_seed(ENCODER_SEED)
+        inp["encoder"] = (torch.randn(inp["feats"].shape[-1], enc_dim, generator=g) / inp["feats"].shape[-1] ** 0.5).numpy()
+    return inp
+
+
+def capture(inp, out_path, per_view=True):
     import torch
     from gsplat import rasterization  # the reference's import (backproject.py:7)
     import gsplat
@@ -37,6 +73,8 @@ def capture(inp, out_path):
     # this function against a stand-in `gsplat` module; a real capture runs on CUDA)
     dev = torch.device(os.environ.get("GWBP_CAPTURE_DEVICE", "cuda"))
     t = {k: torch.from_numpy(np.asarray(inp[k])).to(dev) for k in ("means", "quats", "scales", "opac", "K", "vms", "feats")}
+    if inp.get("encoder") is not None:  # backproject_compressed.py:127: feats @ encoder, then the D = 16 loop
+        t["feats"] = t["feats"] @ torch.from_numpy(np.asarray(inp["encoder"])).to(dev)
     N, (V, H, W, D) = t["means"].shape[0], t["feats"].shape
     F = torch.zeros(N, D, device=dev)
     d = torch.zeros(N, device=dev)
@@ -67,9 +105,10 @@ def capture(inp, out_path):
 
     save = dict(gsplat_version=np.array(gsplat.__version__), torch_version=np.array(torch.__version__),
                 device=np.array(torch.cuda.get_device_name(0) if dev.type == "cuda" else str(dev)),
-                F=F.cpu().numpy(), d=d.cpu().numpy(), out=x.cpu().numpy(),
-                F_views=torch.stack(Fv).cpu().numpy(), d_views=torch.stack(dv).cpu().numpy(),
+                F=F.cpu().numpy(), d=d.cpu().numpy(), out=x.cpu().numpy(), d_views=torch.stack(dv).cpu().numpy(),
                 v0_alphas=alphas0[0, ..., 0].detach().cpu().numpy())
+    if per_view:  # (left out for the wide maps: [V, N, 256] is most of the file)
+        save["F_views"] = torch.stack(Fv).cpu().numpy()
     # packed=True (gsplat's default) returns per-visible-Gaussian arrays + gaussian_ids; both layouts are stored as given
     for key in ("means2d", "radii", "conics", "depths", "gaussian_ids", "camera_ids", "isect_ids", "flatten_ids",
                 "isect_offsets", "tiles_per_gauss"):
@@ -84,19 +123,16 @@ def capture(inp, out_path):
 
 
 def main():
-    capture(dict(np.load(os.path.join(GOLD, "g0.npz"))), os.path.join(GOLD, "gsplat_g0.npz"))
-    try:  # the T1 scene (4 000 Gaussians, 200 x 136, D = 24) needs this repository's seeded generators
-        sys.path.insert(0, ROOT)
-        import torch
-        from gsbp_amd import synthetic as syn
-        cfg = syn.CONFIGS["T1"]
-        means, quats, scales, opac = [x.numpy() for x in syn.activate(syn.make_scene(cfg))]
-        inp = dict(means=means, quats=quats, scales=scales, opac=opac, K=syn.intrinsics(cfg).numpy(),
-                   vms=syn.make_cameras(cfg).numpy(),
-                   feats=torch.stack([syn.make_feature_map(cfg, v) for v in range(cfg.n_views)]).numpy())
-        capture(inp, os.path.join(GOLD, "gsplat_t1.npz"))
-    except ImportError as e:
-        print("T1 capture skipped:", e)
+    for fname, cfgname, dim, enc_dim in CASES:
+        if cfgname is None:
+            inp = dict(np.load(os.path.join(GOLD, "g0.npz")))
+        else:
+            try:
+                inp = case_inputs(cfgname, dim, enc_dim)
+            except ImportError as e:  # (this package's generators need torch only)
+                print(fname, "skipped:", e)
+                continue
+        capture(inp, os.path.join(GOLD, fname), per_view=(dim or 0) < 128)
 
 
 if __name__ == "__main__":

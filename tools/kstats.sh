@@ -3,10 +3,9 @@
 # "product" = the in-tree library).  usage: tools/kstats.sh "<names>" <out dir> [bench args]
 out=${2:-gpurun_out/kstats}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export GWBP_ALLOW_PROFILE=1
 for a in $1; do
-  if [ $a = product ]; then unset GWBP_LIB; else export GWBP_LIB=$PWD/tools/lib/libgwbp_$a.so; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks_$a -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-check $3 > $out/bench_$a.json 2>/dev/null
+  if [ $a = product ]; then LIB=""; else LIB="--lib $PWD/tools/lib/libgwbp_$a.so"; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks_$a -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-check $LIB $3 > $out/bench_$a.json 2>/dev/null
   f=$(find $out/ks_$a -name "*kernel_stats.csv" | head -1)
   echo "== $a  $(python3 -c "import json;print(round(json.load(open('$out/bench_$a.json'))['ms_per_step'],3))") ms/step"
   python3 - $f <<'PY'

@@ -2,10 +2,9 @@
 # On the GPU box: SQ counters of the front-stage kernels while they run beside the scatter kernel (pipelined bench), per library.
 out=${2:-gpurun_out/pmc_front}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export GWBP_ALLOW_PROFILE=1
 for a in $1; do
-  if [ $a = product ]; then unset GWBP_LIB; else export GWBP_LIB=$PWD/tools/lib/libgwbp_$a.so; fi
-  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_$a -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-check $3 > $out/bench_$a.json 2>/dev/null
+  if [ $a = product ]; then LIB=""; else LIB="--lib $PWD/tools/lib/libgwbp_$a.so"; fi
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_$a -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-check $LIB $3 > $out/bench_$a.json 2>/dev/null
   python3 - $out/pmc_$a $a <<'PY'
 import csv,glob,sys,collections
 f=glob.glob(sys.argv[1]+"/**/*counter_collection.csv",recursive=True)[0]

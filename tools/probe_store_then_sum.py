@@ -7,7 +7,7 @@ atomics were plain stores of partial rows and a later pass summed them into F?  
                  (records / Gaussians with weight of view 0, profiles/r3_flush_cache_sim.txt), launched per view on a side stream
                  behind scatter(v) and beside scatter(v + 1), reading its own partial-row buffer and read-modify-writing the REAL F
 
-usage (on the GPU box): GWBP_LIB=... GWBP_ALLOW_PROFILE=1 [GWBP_ABLATE=1] python tools/probe_store_then_sum.py C4|C2 <views> sum|nosum
+usage (on the GPU box): [GWBP_ABLATE=1] python tools/probe_store_then_sum.py C4|C2 <views> sum|nosum [library]
 """
 import ctypes as C
 import os
@@ -18,6 +18,8 @@ import torch
 
 sys.path.insert(0, ".")
 import gsbp_amd  # noqa: E402
+if len(sys.argv) > 4:
+    gsbp_amd._lib.use_library(sys.argv[4], allow_profile=True)
 from gsbp_amd import synthetic as syn  # noqa: E402
 
 name, n_views, mode = sys.argv[1], int(sys.argv[2]), sys.argv[3]
@@ -63,5 +65,5 @@ for rep in range(2):  # the first pass warms the workspaces up (capacity growth,
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n_views * 1e3
     del out
-print(f"{name} {mode:6s} lib={os.path.basename(os.environ.get('GWBP_LIB', 'product'))} ablate={os.environ.get('GWBP_ABLATE', '-')}: "
+print(f"{name} {mode:6s} lib={os.path.basename(sys.argv[4]) if len(sys.argv) > 4 else 'product'} ablate={os.environ.get('GWBP_ABLATE', '-')}: "
       f"{dt:.3f} ms/view over {n_views} views (second pass)")

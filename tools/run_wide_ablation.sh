@@ -1,12 +1,11 @@
 #!/bin/bash
 # On the GPU box: k_scatter_wide ablation table (tools/build_ablations.sh builds), each build alone (--serial) and pipelined.
 out=${1:-gpurun_out/r4_abl}; mkdir -p $out
-export GWBP_ALLOW_PROFILE=1
 for rep in 1 2; do
 for a in ${ABLS:-0 1 9 2 3 4 16}; do
-  export GWBP_LIB=$PWD/tools/lib/libgwbp_abl$a.so
+  LIB="--lib $PWD/tools/lib/libgwbp_abl$a.so"
   for sched in --serial ""; do
-    python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-check --scatter wide $sched > $out/abl${a}${sched}_$rep.json 2>$out/err.txt || tail -3 $out/err.txt
+    python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-check --scatter wide $LIB $sched > $out/abl${a}${sched}_$rep.json 2>$out/err.txt || tail -3 $out/err.txt
     python - "$a" "$sched" $out/abl${a}${sched}_$rep.json <<'PY'
 import json,sys
 j=json.load(open(sys.argv[3]))

@@ -1,10 +1,10 @@
 """Where does k_scatter_wide spend its wave-time?  PROFILE library only (make -C <pkg>/csrc PROFILE=1):
-GWBP_LIB=tools/lib/libgwbp_profile.so GWBP_ALLOW_PROFILE=1 python tools/stamp_scatter.py [views]"""
+python tools/stamp_scatter.py [views]"""
 import ctypes as C, os, sys
 sys.path.insert(0, ".")
-os.environ.setdefault("GWBP_LIB", os.path.abspath("tools/lib/libgwbp_profile.so"))
-os.environ.setdefault("GWBP_ALLOW_PROFILE", "1")
 import torch, gsbp_amd
+from gsbp_amd import _lib
+_lib.use_library(os.path.abspath("tools/lib/libgwbp_profile.so"), allow_profile=True)
 from gsbp_amd import synthetic as syn
 dev = torch.device("cuda:0")
 cfg = syn.CONFIGS["C2"]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the GPU box: pipeline knobs of bench.py (workspaces in flight, wave priority of the front kernels, stream priority).
-# usage: [GWBP_LIB=...] tools/sweep_knobs.sh "<args 1>" "<args 2>" ...
+# usage: tools/sweep_knobs.sh "<args 1>" "<args 2>" ...
 for args in "$@"; do
   python bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-check $args > /tmp/b.json 2>/dev/null
   python - "$args" <<'PY'
