@@ -127,7 +127,8 @@ class ViewPipeline:
 
     def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None,
                  allow_wide: bool = True, scatter_workgroups: Optional[int] = None, side_priority: int = -1,
-                 front_priority: Optional[bool] = None, fuse_small: bool = True, side_streams: Optional[int] = None):
+                 front_priority: Optional[bool] = None, fuse_small: bool = True, side_streams: Optional[int] = None,
+                 view_per_stream: Optional[bool] = None):
         self.dev = torch.device(device)
         from . import _lib
         if not _lib.hw_queues_ok():
@@ -156,8 +157,11 @@ class ViewPipeline:
         # On small images the kernel runs a wave per QUARTER tile (four short blend chains per tile instead of one long
         # one) and takes up to 32 channels; on large ones it needs two workspaces' worth of schedule (len(eng) == 2).
         small_image = Engine.fused_max_dim(width, height) == Engine.FUSED_MAX_DIM_SMALL
+        # view_per_stream=True: large images too run every view entirely on a stream of its own (K > 2 workspaces): the fused
+        # kernels of consecutive views then overlap at their edges (measured for the compressed variant)
         self.fuse_small = (bool(fuse_small) and scatter_dim is not None
-                           and scatter_dim <= Engine.fused_max_dim(width, height) and (small_image or len(self.eng) == 2))
+                           and scatter_dim <= Engine.fused_max_dim(width, height)
+                           and (small_image or len(self.eng) == 2 or bool(view_per_stream)))
         self.front_priority = front_priority  # None: raised wave priority for the front exactly when the wide kernel runs
         self.choose_scatter_kernel(None, None)
         K = len(self.eng)
@@ -166,7 +170,7 @@ class ViewPipeline:
         # and a view runs ENTIRELY on it -- project, sort, blend+scatter in stream order, K views in flight, one event per
         # view (the map must be ready) instead of two, and the fused kernels of consecutive views overlap.  F and d take
         # atomics anyway.  (With separate blend and scatter kernels this schedule was measured to change nothing.)
-        self.independent = K > 2 and self.fuse_small
+        self.independent = K > 2 and self.fuse_small and view_per_stream is not False
         n_side = K if self.independent else max(1, K - 1)
         if side_streams is not None and not self.independent:
             n_side = max(1, min(int(side_streams), K - 1))
@@ -306,6 +310,9 @@ class ViewPipeline:
         fused = not blended and encoder is None and upsample is None and Engine.can_blend_scatter(feats)
         if fused:
             e.blend_scatter(view, feats, F, d, scale_f, scale_d)
+        elif not blended and encoder is not None and upsample is None and Engine.can_blend_scatter_encoded(feats, encoder):
+            # the compressed variant in ONE kernel: encoder in the tile prologue, then blend + scatter from registers
+            e.blend_scatter_encoded(view, feats, encoder, F, d, scale_f, scale_d)
         else:
             if not blended:  # the map does not suit the fused kernel after all: blend here, then the usual scatter
                 e.blend_weights(view)
@@ -380,7 +387,7 @@ class ViewPipeline:
 OVERFLOW_CHECK_EVERY = 32
 
 
-def pipeline_depth(n_gaussians: int, width: int, height: int, dim: Optional[int] = None) -> int:
+def pipeline_depth(n_gaussians: int, width: int, height: int, dim: Optional[int] = None, encoder_in_blend: bool = False) -> int:
     """Workspaces (views in flight) of the ViewPipeline.
     Small scenes: 4 -- three front stages in flight on three side streams: a view is ~35 dependent launches of 5-20 us each
     and the chain, not the chip, is the limit (C1: 0.49 -> 0.19 ms/view; 5 and more lose again: the streams start sharing
@@ -389,8 +396,15 @@ def pipeline_depth(n_gaussians: int, width: int, height: int, dim: Optional[int]
     pass, which leaves the ONE front stage beside it too few idle slots to keep up (C2 at depth 2: front 3.82 ms against a
     3.70 ms scatter); with two fronts in flight the scatter kernel is the long stage again (3.91 -> 3.71 ms/view; C4
     10.15 -> 10.02; a fourth workspace adds nothing).  Maps narrow enough for the fused blend + scatter kernel (`dim` <= 16 on
-    large images, the compressed variant) keep 2: that kernel's schedule is built for two workspaces (C5: 1.47 against 1.98)."""
+    large images, the compressed variant) keep 2: that kernel's schedule is built for two workspaces (C5: 1.47 against 1.98).
+    `encoder_in_blend` (round 5: the compressed variant's encoder inside the fused kernel's tile prologue,
+    gwbp_blend_scatter_encoded): 4, every view entirely on a stream of its own -- one such kernel runs its HBM-bound prologues
+    and its issue-bound blend loops in lockstep (1.29 ms alone = encoder 0.58 + blend 0.70), the kernels of four views in
+    flight overlap them (C5: 1.27-1.33 ms/view; 3 workspaces 1.37-1.41, 5: 1.39-1.41, 6: 1.36-1.37; the separate encoder one
+    view ahead: 1.38-1.44)."""
     if n_gaussians <= 250_000 and width * height <= 1_000_000:
+        return 4
+    if encoder_in_blend:
         return 4
     if dim is not None and dim <= Engine.fused_max_dim(width, height):
         return 2
@@ -403,7 +417,8 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                          views: Optional[Sequence[int]] = None, view_fn=None, pipeline: bool = True,
                          return_partials: bool = False, verbose: bool = False, upsample: Optional[str] = None,
                          gather: bool = True, allow_wide: bool = True, fuse_encoder: bool = False,
-                         fuse_small: bool = True, feature_fn_stream_safe: bool = False):
+                         fuse_small: bool = True, feature_fn_stream_safe: bool = False,
+                         encoder_in_blend: Optional[bool] = None):
     """Build the [N, dim_out] per-Gaussian feature field.
 
     means/quats/scales/opacities: post-activation Gaussians (backproject.py:55-57), device tensors.
@@ -421,6 +436,10 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     is read once, no [H,W,dim_out] intermediate) when the map's layout allows; False (default, measured faster in the
     three-stream pipeline: C5 2.19 vs 2.29 ms/view; the fused kernel wins on one stream, 2.51 vs 2.70) = a separate encode
     kernel one view ahead on a third stream (gwbp_encode_map).
+    encoder_in_blend: with `encoder`, apply it inside the fused blend + scatter kernel's tile prologue (gwbp_blend_scatter_encoded:
+    one kernel per view, no [H,W,dim_out] map, four views in flight on streams of their own).  None (default) = whenever the
+    first map's layout allows and fuse_small is on (C5: 1.27-1.33 against 1.38-1.44 ms/view for the encoder one view ahead);
+    False = never.
     fuse_small: maps of at most 16 channels (after the encoder) are blended AND scattered by one kernel
     (gwbp_blend_scatter: no weight store, no scatter kernel; C5 1.96 -> 1.42 ms/view); False keeps the two-kernel form.
     feature_fn_stream_safe: STREAM CONTRACT of feature_fn.  False (default): feature_fn runs on the caller's current stream
@@ -457,9 +476,14 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
         eng = engine or Engine(n, width, height, device=dev, tight_binning=True)  # same F and d, shorter tile lists
         for attempt in range(6):  # a capacity overflow invalidates the accumulators: grow the workspace, start over
             if pipeline and len(my_views) > 1:
-                depth = pipeline_depth(n, width, height, d_out) if pipeline is True else max(2, int(pipeline))
+                first_map = feature_fn(my_views[0]) if encoder is not None else None
+                enc_blend = (encoder is not None and fuse_small and not fuse_encoder and upsample is None
+                             and encoder_in_blend is not False and Engine.can_blend_scatter_encoded(first_map, encoder))
+                depth = (pipeline_depth(n, width, height, d_out, encoder_in_blend=enc_blend) if pipeline is True
+                         else max(2, int(pipeline)))
                 pipe = ViewPipeline(n, width, height, dev, scatter_dim=d_out,
                                     allow_wide=allow_wide, fuse_small=fuse_small and not (fuse_encoder and encoder is not None),
+                                    view_per_stream=True if (enc_blend and depth > 2) else None,
                                     engines=[eng] + [Engine(n, width, height, device=dev, tight_binning=eng.tight_binning,
                                                             isect_cap=eng.isect_cap, pair_cap=eng.pair_cap)
                                                      for _ in range(depth - 1)])
@@ -470,8 +494,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                 # stream while view v is scattered (two full-width maps are alive at a time)
                 fused = None  # decided on the first map: its layout must suit gwbp_scatter_encoded
                 ahead = None
-                if encoder is not None:
-                    first_map = feature_fn(my_views[0])
+                if encoder is not None and not enc_blend:
                     fused = fuse_encoder and upsample is None and Engine.can_fuse_encoder(first_map, encoder)
                     ahead = (first_map, None) if fused else pipe.encode_ahead(first_map, encoder)
                 probe = None  # (pinned copy of the counters, event): an overflow costs at most OVERFLOW_CHECK_EVERY views
@@ -492,6 +515,11 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                         probe = pipe.stats_async()
                     if i + pipe.lookahead < len(my_views):
                         pipe.front(views[i + pipe.lookahead], means, quats, scales, opacities, d, sd)
+                    if enc_blend:
+                        # encoder + blend + scatter of the view in one kernel, on the view's own stream
+                        feats = first_map if i == 0 else feature_fn(v)
+                        pipe.scatter(feats, F, d, sf, sd, encoder=encoder)
+                        continue
                     if fused:
                         # the encoder is applied inside the scatter kernel's slab staging: no [H,W,dim_out] map at all
                         feats = ahead[0] if i == 0 else feature_fn(v)

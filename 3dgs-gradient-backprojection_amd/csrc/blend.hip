@@ -34,8 +34,16 @@ constexpr int kBatch = 64;
 //            the tile's pixels held in registers (D <= 16: 4 pixels x 16 channels = 64 VGPRs per lane) and added to F / d
 //            with one atomic instruction -- the small-D variants (backproject_compressed.py:127-165: D = 16) then need
 //            neither the 0.8 GB store nor a scatter kernel.
-enum BlendMode { kStore = 0, kHalves = 1, kFused = 2 };
+//   kFusedEnc: kFused whose 16-channel pixels are COMPUTED by the kernel from a K-channel map and a [K, n <= 16] encoder
+//            (backproject_compressed.py:127 inside the tile's prologue): the wave streams its tile's 256 pixels x K channels once
+//            through the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, the same k-ordered chain as k_encode_map) and the
+//            results land -- after a 4 x 4 exchange between the rows of 16 lanes -- in the registers kFused loads them into.
+//            No [H, W, 16] map, no encoder kernel, and the HBM stream of one wave's prologue overlaps with the other waves'
+//            blend loops on the same SIMD instead of two kernels competing for wave slots.
+enum BlendMode { kStore = 0, kHalves = 1, kFused = 2, kFusedEnc = 3 };
 constexpr int kFusedCh = 16;
+constexpr int kEncWaves = 8;    // kFusedEnc: tiles (waves) per workgroup sharing one LDS copy of the encoder
+constexpr int kEncMaxK = 512;   // ... whose K x 16 floats take at most 32 KB
 
 struct FusedArgs { // kFused only
     const float *feats; // feats[y * fs_y + x * fs_x + c], c < D
@@ -44,6 +52,8 @@ struct FusedArgs { // kFused only
     int vec4;    // rows may be read as float4 (D % 4 == 0, 16-B aligned base and strides)
     float scale_f;
     float *F;
+    const float *enc; // kFusedEnc: [enc_k, D] row-major; feats then has enc_k channels per pixel
+    int enc_k;
 };
 
 // Sum of 16 per-lane values over the 64 lanes, transposed: lane l returns the wave total of value c(l),
@@ -150,8 +160,30 @@ __device__ __forceinline__ void store_pair_masked(u64 mask, WPair *dst, const WP
                  : "memory");
 }
 
-template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_blend(ViewDev V, const u32 *__restrict__ tile_offsets,
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+// Exchange between the four rows of 16 lanes: on entry register x[rho] of lane row g holds block (rho, g); on exit register x[g]
+// of lane row rho holds it (a 4 x 4 transpose of register index against lane row: two v_permlane16_swap, two v_permlane32_swap).
+__device__ __forceinline__ void rows_transpose4(float (&x)[4])
+{
+#if __HIP_DEVICE_COMPILE__
+    auto sw16 = [](float &a, float &b) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(a), __float_as_int(b), false, false);
+        a = __int_as_float(r[0]), b = __int_as_float(r[1]);
+    };
+    auto sw32 = [](float &a, float &b) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(b), false, false);
+        a = __int_as_float(r[0]), b = __int_as_float(r[1]);
+    };
+    sw16(x[0], x[1]); // rows 1 <-> 0 and 3 <-> 2 of the pair
+    sw16(x[2], x[3]);
+    sw32(x[0], x[2]); // rows {2, 3} <-> {0, 1} of the pair
+    sw32(x[1], x[3]);
+#endif
+}
+
+template <int MODE, int WAVES = 1>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_blend(ViewDev V, const u32 *__restrict__ tile_offsets,
                                               const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
                                               Counters *__restrict__ ctr, Header *__restrict__ headers,
                                               u32 *__restrict__ hdr_count, WPair *__restrict__ wpool, u32 pair_cap,
@@ -166,14 +198,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     (void)dbg_arg;
 #endif
     constexpr bool WSUM = MODE == kHalves; // the record's weight sum in its header (+ d[gid] right here)
+    constexpr bool FUSED = MODE == kFused || MODE == kFusedEnc;
     front_priority(prio);
-    __shared__ float4 s_a[kBatch]; // mx, my, opac, gid bits
-    __shared__ float4 s_b[kBatch]; // ca, cb, cc, strip mask
-    __shared__ float s_thr[kBatch]; // ln(255 o) + margin: sigma above this cannot reach alpha >= 1/255
+    __shared__ float4 s_a_[WAVES][kBatch]; // mx, my, opac, gid bits
+    __shared__ float4 s_b_[WAVES][kBatch]; // ca, cb, cc, strip mask
+    __shared__ float s_thr_[WAVES][kBatch]; // ln(255 o) + margin: sigma above this cannot reach alpha >= 1/255
+    const int wave = WAVES > 1 ? (int)uniform(threadIdx.x >> 6) : 0;
+    float4 *const s_a = s_a_[wave], *const s_b = s_b_[wave];
+    float *const s_thr = s_thr_[wave];
 
-    const int tile = (int)tile_order[blockIdx.x]; // longest lists first
+    const int n_tiles_all = V.tile_w * V.tile_h;
+    const int slot = (int)blockIdx.x * WAVES + wave;
+    if constexpr (MODE == kFusedEnc) {
+        // the encoder, re-ordered per MFMA step like k_encode_map's: [K/16][i][kq][n] <- enc[16 j + 4 kq + i][n]
+        extern __shared__ __attribute__((aligned(16))) float s_enc[];
+        for (int idx = threadIdx.x; idx < fu.enc_k * kFusedCh; idx += 64 * WAVES) {
+            const int n = idx & 15, kq = (idx >> 4) & 3, i = (idx >> 6) & 3, j = idx >> 8;
+            s_enc[idx] = n < fu.D ? fu.enc[(int64_t)(16 * j + 4 * kq + i) * fu.D + n] : 0.f;
+        }
+        __syncthreads();
+    }
+    if (WAVES > 1 && slot >= n_tiles_all)
+        return; // (behind the only barrier of the kernel: the waves of a workgroup are independent from here on)
+    const int tile = (int)tile_order[slot]; // longest lists first
     const int tx = tile % V.tile_w, ty = tile / V.tile_w;
-    const int lane = threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63u);
     const int ix = tx * kTile + (lane & 15), iy0 = ty * kTile + (lane >> 4);
     const float px = (float)ix + 0.5f;
     const u32 beg = tile_offsets[tile], end = tile_offsets[tile + 1];
@@ -202,7 +251,84 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 
     // kFused: the lane's four pixels, kFusedCh channels each, stay in registers for the whole tile (pixels outside the
     // image never get a weight: T = 0; they read a clamped address)
-    float f[MODE == kFused ? 4 : 1][MODE == kFused ? kFusedCh : 1];
+    float f[FUSED ? 4 : 1][FUSED ? kFusedCh : 1];
+    if constexpr (MODE == kFusedEnc) {
+        // f[q][c] = sum_k feats[pixel (ix, iy0 + 4 q)][k] enc[k][c].  One MFMA tile = ONE TILE ROW: M = the 16 encoder outputs
+        // (A operand: lane (n = lane % 16, kq = lane / 16) reads its encoder value from LDS), N = the row's 16 pixels (B operand:
+        // lane (column = lane % 16, kq) holds the float4 feats[pixel][16 j + 4 kq ..] of k-block j, component i feeds step i),
+        // so the result registers of lane (column, g) are outputs 4 g .. 4 g + 3 of that row's pixel in ITS column.  Four
+        // rows (one quarter) are accumulated side by side -- the four encoder reads of a k-block serve 16 MFMAs -- and a
+        // 4 x 4 exchange between the lane rows hands every lane all 16 outputs of its own pixel (row 4 q + lane / 16).
+        extern __shared__ __attribute__((aligned(16))) float s_enc[];
+        const int kq = lane >> 4;
+        const int cx = min(ix, V.W - 1);
+        const int nb = fu.enc_k >> 4;
+        const float *ebase = s_enc + lane;
+        // address = wave-uniform row base (scalar registers) + ONE per-lane byte offset: four 64-bit pointers per lane would cost
+        // eight registers of the 128 the kernel may use at four waves per SIMD
+        const u32 lane_off = (u32)(((int64_t)cx * fu.fs_x + 4 * kq) * (int64_t)sizeof(float));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const char *rowp[4];
+#pragma unroll
+            for (int rho = 0; rho < 4; ++rho)
+                rowp[rho] = reinterpret_cast<const char *>(fu.feats + (int64_t)min(ty * kTile + 4 * q + rho, V.H - 1) * fu.fs_y);
+            auto ld = [&](int rho, int j) __attribute__((always_inline)) -> float4 {
+                return *reinterpret_cast<const float4 *>(rowp[rho] + ((size_t)lane_off + (size_t)(64 * j)));
+            };
+            f32x4m R[4];
+#pragma unroll
+            for (int rho = 0; rho < 4; ++rho)
+                R[rho] = f32x4m{0.f, 0.f, 0.f, 0.f};
+            constexpr int kPF = 2; // k-blocks in flight: 2 x 4 rows x 16 B per lane = 8 KB per wave
+            float4 b[kPF][4];
+#pragma unroll
+            for (int u = 0; u < kPF; ++u)
+#pragma unroll
+                for (int rho = 0; rho < 4; ++rho)
+                    b[u][rho] = ld(rho, min(u, nb - 1));
+            for (int j0 = 0; j0 < nb; j0 += kPF) {
+#pragma unroll
+                for (int u = 0; u < kPF; ++u) {
+                    const int j = j0 + u;
+                    if (j >= nb)
+                        break;
+                    float4 bv[4];
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho)
+                        bv[rho] = b[u][rho];
+                    if (j + kPF < nb) {
+#pragma unroll
+                        for (int rho = 0; rho < 4; ++rho)
+                            b[u][rho] = ld(rho, j + kPF);
+                    }
+                    const float *e = ebase + j * 256; // (kq, n) = lane; steps i are 64 floats apart
+                    const float a0 = e[0], a1 = e[64], a2 = e[128], a3 = e[192];
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho)
+                        R[rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[rho].x, R[rho], 0, 0, 0);
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho)
+                        R[rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[rho].y, R[rho], 0, 0, 0);
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho)
+                        R[rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bv[rho].z, R[rho], 0, 0, 0);
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho)
+                        R[rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bv[rho].w, R[rho], 0, 0, 0);
+                }
+            }
+            // R[rho][r] of lane row g = output 4 g + r of the pixel (column, row 4 q + rho)  ->  f[q][4 g + r] of lane row rho
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x[4] = {R[0][r], R[1][r], R[2][r], R[3][r]};
+                rows_transpose4(x);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    f[q][4 * g + r] = x[g];
+            }
+        }
+    }
     if constexpr (MODE == kFused) {
         const int cx = min(ix, V.W - 1);
 #pragma unroll
@@ -229,7 +355,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     size_t out_mul = 0;
     float out_scale = 0.f;
     bool out_on = false;
-    if constexpr (MODE == kFused) {
+    if constexpr (FUSED) {
         out_base = lane < 16 ? fu.F + my_ch : d_out;
         out_mul = lane < 16 ? (size_t)fu.D : (size_t)1;
         out_scale = lane < 16 ? fu.scale_f : scale_d;
@@ -341,7 +467,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 base[q] = total;
                 total += cnt[q];
             }
-            if constexpr (MODE == kFused) {
+            if constexpr (FUSED) {
                 float p[kFusedCh], wl = 0.f;
 #pragma unroll
                 for (int c = 0; c < kFusedCh; ++c)
@@ -435,9 +561,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         }
     }
     if (lane == 0) {
-        if (MODE == kFused && blockIdx.x == 0)
+        if (FUSED && slot == 0)
             ctr->blend_kind = kBlendFused; // (no k_pool_stats launch behind the fused kernel: the pool is untouched)
-        hdr_count[tile] = MODE == kFused ? 0u : hdr_n; // kFused: the store stays empty
+        hdr_count[tile] = FUSED ? 0u : hdr_n; // kFused: the store stays empty
         if (hdr_n)
             atomicAdd(&ctr->n_headers, hdr_n);
         if (npairs)
@@ -655,16 +781,26 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
 {
     const bool fused = M != nullptr;
     FusedArgs fu = {};
+    const bool fused_enc = fused && M->enc != nullptr;
     if (fused) {
-        const int cap = V.tile_w * V.tile_h <= kQuarterMaxTiles ? kQuarterMaxCh : kFusedCh;
+        const int cap = (!fused_enc && V.tile_w * V.tile_h <= kQuarterMaxTiles) ? kQuarterMaxCh : kFusedCh;
         if (D < 1 || D > cap)
             return set_error(GWBP_EINVAL, "gwbp_blend_scatter: D must be 1..%d for this image size (got %d)", cap, D);
-        if (M->fs_c != 1 || M->ymap || M->xmap || M->enc)
+        if (M->fs_c != 1 || M->ymap || M->xmap)
             return set_error(GWBP_EINVAL, "gwbp_blend_scatter: a full-resolution map with unit channel stride is required");
         if (!M->p || !F)
             return set_error(GWBP_EINVAL, "null feats / F");
         fu.feats = M->p, fu.fs_y = M->fs_y, fu.fs_x = M->fs_x, fu.D = D, fu.scale_f = scale_f, fu.F = F;
         fu.vec4 = (D % 4 == 0 && M->fs_y % 4 == 0 && M->fs_x % 4 == 0 && (reinterpret_cast<uintptr_t>(M->p) & 15) == 0) ? 1 : 0;
+        if (fused_enc) {
+            // the tile prologue reads every pixel as float4 k-blocks of 16 channels: same domain as gwbp_encode_map, K <= 512
+            if (M->enc_k < 16 || M->enc_k % 16 != 0 || M->enc_k > kEncMaxK)
+                return set_error(GWBP_EINVAL, "gwbp_blend_scatter_encoded: K must be a multiple of 16 in 16..%d (got %d)", kEncMaxK,
+                                 M->enc_k);
+            if (M->fs_y % 4 != 0 || M->fs_x % 4 != 0 || (reinterpret_cast<uintptr_t>(M->p) & 15) != 0 || M->fs_x < M->enc_k)
+                return set_error(GWBP_EINVAL, "gwbp_blend_scatter_encoded: pixels must be 16-B aligned runs of K contiguous channels");
+            fu.enc = M->enc, fu.enc_k = M->enc_k;
+        }
     }
     if (!fused && d && (L.flags & GWBP_FLAG_NARROW_SCATTER))
         return set_error(GWBP_EINVAL, "gwbp_blend_weights_d needs a blend without GWBP_FLAG_NARROW_SCATTER (no weight sums)");
@@ -678,7 +814,12 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
     hipLaunchKernelGGL(k_blend<H>, dim3(n_tiles), dim3(64), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d,  \
                        W.counters, W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, W.tile_order, alphas,  \
                        ablate, prio, d, scale_d, fu)
-    if (fused && n_tiles <= kQuarterMaxTiles) {
+    if (fused_enc) {
+        const size_t lds = (size_t)fu.enc_k * kFusedCh * sizeof(float);
+        hipLaunchKernelGGL((k_blend<kFusedEnc, kEncWaves>), dim3((n_tiles + kEncWaves - 1) / kEncWaves), dim3(64 * kEncWaves), lds, s,
+                           V, W.tile_offsets, W.vals[fin], W.g2d, W.counters, W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap,
+                           W.shards, W.tile_order, alphas, ablate, prio, d, scale_d, fu);
+    } else if (fused && n_tiles <= kQuarterMaxTiles) {
 #define GWBP_QUARTER(C)                                                                                               \
     hipLaunchKernelGGL(k_blend_scatter_quarter<C>, dim3(4 * n_tiles), dim3(64), 0, s, V, W.tile_offsets, W.vals[fin], W.g2d, \
                        W.counters, W.hdr_count, W.tile_order, alphas, ablate, prio, d, scale_d, fu)

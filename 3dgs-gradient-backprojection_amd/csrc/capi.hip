@@ -319,6 +319,25 @@ int gwbp_blend_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_
     return launch_blend(L, W, V, alphas, d, scale_d, static_cast<hipStream_t>(stream), &M, D, scale_f, F);
 }
 
+int gwbp_blend_scatter_encoded(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                               const float *feats, int64_t fs_y, int64_t fs_x, int32_t K, const float *encoder, int32_t n_out,
+                               float scale_f, float scale_d, float *F, float *d, float *alphas, void *stream)
+{
+    Layout L;
+    Ws W;
+    ViewDev V;
+    int rc = bind_workspace(caps, workspace, workspace_bytes, &L, &W);
+    if (rc)
+        return rc;
+    if ((rc = make_view(view_host, caps, &V)))
+        return rc;
+    if (!encoder)
+        return set_error(GWBP_EINVAL, "null encoder");
+    FeatMap M{feats, fs_y, fs_x, 1, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    M.enc = encoder, M.enc_k = K;
+    return launch_blend(L, W, V, alphas, d, scale_d, static_cast<hipStream_t>(stream), &M, n_out, scale_f, F);
+}
+
 int gwbp_accumulate_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                       float scale_d, float *d, void *stream)
 {

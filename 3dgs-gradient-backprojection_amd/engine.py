@@ -229,6 +229,39 @@ class Engine:
         return alphas
 
     @staticmethod
+    def can_blend_scatter_encoded(feats: torch.Tensor, encoder: torch.Tensor) -> bool:
+        """Shapes gwbp_blend_scatter_encoded takes: [H,W,K] float32 with channel-contiguous 16-B aligned pixels, K % 16 == 0,
+        16 <= K <= 512, at most 16 outputs (the reference's encoder is 512 -> 16, backproject_compressed.py:26,127)."""
+        if feats.dim() != 3 or encoder.dim() != 2 or feats.shape[2] != encoder.shape[0]:
+            return False
+        sy, sx, sc = feats.stride()
+        K, n = encoder.shape
+        return (feats.is_cuda and feats.dtype == torch.float32 and encoder.dtype == torch.float32 and 1 <= n <= 16
+                and K % 16 == 0 and 16 <= K <= 512 and sc == 1 and sy % 4 == 0 and sx % 4 == 0 and sy >= 0 and sx >= K
+                and feats.data_ptr() % 16 == 0)
+
+    def blend_scatter_encoded(self, view, feats, encoder, F, d, scale_f=1.0, scale_d=1.0, want_alphas=False):
+        """blend_scatter(view, feats @ encoder, ...) of the compressed variant (backproject_compressed.py:127-165) in ONE
+        kernel: every tile's wave streams its 256 pixels x K channels once through the matrix cores (exact fp32, the same
+        chain as encode_map) into the registers the fused blend + scatter works from -- no [H,W,n] map, no encoder kernel, no
+        weight store."""
+        if not self.can_blend_scatter_encoded(feats, encoder):
+            raise GwbpError("blend_scatter_encoded: [H,W,K] float32 channel-contiguous 16-B aligned map, K % 16 == 0, "
+                            f"16 <= K <= 512, <= 16 outputs required, got {tuple(feats.shape)} strides {tuple(feats.stride())} "
+                            f"@ {tuple(encoder.shape)}")
+        if feats.shape[0] != view.height or feats.shape[1] != view.width:
+            raise GwbpError(f"feature map must be [{view.height},{view.width},K], got {tuple(feats.shape)}")
+        sy, sx, _ = feats.stride()
+        K, n = encoder.shape
+        self._check_acc(F, d, n)
+        enc = encoder.contiguous()
+        alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
+        self._halves = False  # the store is empty: no scatter kernel has anything to read
+        self._call("gwbp_blend_scatter_encoded", *self._args(), C.byref(view), ptr(feats), sy, sx, K, ptr(enc), n,
+                   C.c_float(scale_f), C.c_float(scale_d), ptr(F), ptr(d), ptr(alphas), self._stream())
+        return alphas
+
+    @staticmethod
     def _feat_strides(feats: torch.Tensor, view, lowres: bool = False) -> Tuple[int, int, int, int]:
         if feats.dim() != 3 or (not lowres and (feats.shape[0] != view.height or feats.shape[1] != view.width)):
             raise GwbpError(f"feature map must be [H,W,D] = [{view.height},{view.width},D], got {tuple(feats.shape)}")

@@ -62,8 +62,9 @@ def main():
     ap.add_argument("--side-prio", type=int, default=-1, help="HIP priority of the front stage's stream")
     ap.add_argument("--front-prio", choices=("auto", "on", "off"), default="auto",
                     help="raised wave priority for the front-stage kernels (auto: with the 256-channel scatter kernel)")
-    ap.add_argument("--encoder", choices=("fused", "ahead"), default="ahead",
-                    help="C5: encoder inside the scatter kernel's slab staging, or a separate kernel one view ahead")
+    ap.add_argument("--encoder", choices=("fused", "ahead", "blend"), default="blend",
+                    help="C5: encoder inside the small-D scatter kernel's slab staging (fused), a separate kernel one view ahead "
+                         "(ahead), or inside the fused blend + scatter kernel's tile prologue (blend: gwbp_blend_scatter_encoded)")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for the one-GPU check)")
     ap.add_argument("--one-device", action="store_true",
                     help="every rank uses cuda:0 (checks the N > 1 bookkeeping on a one-GPU box together with --dist-backend gloo)")
@@ -84,6 +85,8 @@ def main():
                     help="STRONG scaling (BASELINE.json configs[2]): the same T views sharded r, r+R, ... over the ranks; "
                          "overrides --steps (each rank times its ceil/floor(T / world) views)")
     ap.add_argument("--serial", action="store_true", help="one stream, no overlap of front(v+1) with scatter(v)")
+    ap.add_argument("--view-per-stream", action="store_true",
+                    help="large images with narrow maps: every view entirely on a stream of its own (with --depth > 2)")
     ap.add_argument("--lib", default=None,
                     help="DEVELOPER: another build of the library (tools/lib/libgwbp_<name>.so: A/B, PROFILE or ablation builds, "
                          "results possibly INVALID) instead of the in-tree one; recorded in the line as config.library")
@@ -168,13 +171,15 @@ def main():
         eng.set_narrow_scatter(not (D % 256 == 0 and allow_wide))
         pipe, accum = None, torch.zeros(32, dtype=torch.uint8, device=dev)
     else:
-        depth = args.depth or gsbp_amd.backproject.pipeline_depth(N, W, H, D)
+        enc_blend = encoder is not None and args.encoder == "blend" and not args.no_fuse_small
+        depth = args.depth or gsbp_amd.backproject.pipeline_depth(N, W, H, D, encoder_in_blend=enc_blend)
         more = [gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap, tight_binning=tight)
                 for _ in range(depth - 1)]
         pipe = gsbp_amd.ViewPipeline(N, W, H, dev, engines=[eng] + more, scatter_dim=D, allow_wide=allow_wide,
                                      scatter_workgroups=args.pipe_wgs, side_priority=args.side_prio,
                                      front_priority=None if args.front_prio == "auto" else args.front_prio == "on",
-                                     fuse_small=not args.no_fuse_small, side_streams=args.side_streams)
+                                     fuse_small=not args.no_fuse_small, side_streams=args.side_streams,
+                                     view_per_stream=True if (args.view_per_stream or (enc_blend and depth > 2)) else None)
         accum = pipe.accum
         if args.enc_wgs_per_cu:
             pipe.ENCODER_WORKGROUPS_PER_CU = args.enc_wgs_per_cu
@@ -208,7 +213,7 @@ def main():
         k = i - args.warmup
         feats, after, fenc = pool[i % args.pool], None, None
         if encoder is not None:
-            if args.encoder == "fused":
+            if args.encoder in ("fused", "blend"):
                 fenc = encoder
             elif args.serial:
                 feats = eng.encode_map(feats, encoder)
@@ -217,10 +222,13 @@ def main():
         if args.serial:  # one stream, one workspace: the pre-pipelining schedule
             eng.project(views[i], means, quats, scales, opac)
             eng.bin_sort(views[i])
-            if fused_small and fenc is None:
+            if fused_small and (fenc is None or args.encoder == "blend"):
                 if 0 <= k < args.steps:
                     ev[k][2].record()
-                eng.blend_scatter(views[i], feats, F, d)
+                if fenc is not None:
+                    eng.blend_scatter_encoded(views[i], feats, fenc, F, d)
+                else:
+                    eng.blend_scatter(views[i], feats, F, d)
                 eng.accumulate_stats(accum)
                 if 0 <= k < args.steps:
                     ev[k][3].record()
@@ -349,18 +357,23 @@ def main():
         pairs_view = stats["n_pairs"] / args.steps
         # algorithmic bytes of ONE scatter launch: feature map read once + RMW of the F rows
         # and d entries of the Gaussians visible in the view (4HWD + 8 N_vis (D+1))
-        b_scatter = 4.0 * H * W * D + 8.0 * n_vis * (D + 1)
+        # (encoder inside the kernel: the dominant kernel reads the FULL-width map once, SURVEY.md 8(d) "plus 3.47 GB if the
+        # 512-d map is read and encoded on the fly")
+        d_read = D_in if (encoder is not None and args.encoder in ("blend", "fused")) else D
+        b_scatter = 4.0 * H * W * d_read + 8.0 * n_vis * (D + 1)
         b_view = b_scatter + 44.0 * N + 24.0 * n_isect
         achieved = b_scatter / (t_scatter * 1e-3) / 1e9
         # The STRICT count: SURVEY.md 8(d) words the third term as the F rows "of Gaussians that RECEIVE WEIGHT in this
         # view"; n_visible (survives culling) is what its formula and probe number use and is ~45 % larger at C2.  n_touched =
         # Gaussians with d_v > 0, counted per timed view by the post-run check pass (exact, outside the timed region).
         n_touched = (checked or {}).get("n_touched_per_view")
-        b_strict = 4.0 * H * W * D + 8.0 * n_touched * (D + 1) if n_touched else None
+        b_strict = 4.0 * H * W * d_read + 8.0 * n_touched * (D + 1) if n_touched else None
         # PMC counters cannot be collected from inside this process: `traffic` is the HBM byte count per launch of the
         # SAME kernel and workload from the committed rocprofv3 --pmc passes (tools/profile_round.sh, separate runs)
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-        scatter_kernel = (("k_blend_scatter_quarter" if gsbp_amd.Engine.fused_max_dim(W, H) > gsbp_amd.Engine.FUSED_MAX_DIM
+        scatter_kernel = ("k_blend<kFusedEnc> (encoder + blend + scatter in one kernel, no encoded map, no weight store)"
+                          if fused_small and encoder is not None and args.encoder == "blend" else
+                          ("k_blend_scatter_quarter" if gsbp_amd.Engine.fused_max_dim(W, H) > gsbp_amd.Engine.FUSED_MAX_DIM
                            else "k_blend<kFused>") + " (blend + scatter in one kernel, no weight store)" if fused_small else
                           "k_scatter_wide" if scatter_choice == "wide" else
                           "k_scatter_full" if (D % 128 == 0 or D <= 64) else "k_scatter")

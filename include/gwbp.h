@@ -141,6 +141,16 @@ int gwbp_blend_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_
                        const float *feats, int64_t fs_y, int64_t fs_x, int32_t D, float scale_f, float scale_d,
                        float *F, float *d, float *alphas, void *stream);
 
+/* gwbp_blend_scatter of feats[H, W, K] @ encoder[K, n_out] (backproject_compressed.py:127-165 in ONE kernel): every tile's wave
+ * first streams its 256 pixels x K channels once through the matrix cores (exact fp32, the k-ordered chain of gwbp_encode_map)
+ * and keeps the n_out <= 16 outputs per pixel in registers -- no [H, W, n_out] map, no encoder kernel -- then blends and
+ * scatters like gwbp_blend_scatter.  feats[y * fs_y + x * fs_x + k]: channel-contiguous 16-B aligned pixels, K % 16 == 0,
+ * 16 <= K <= 512; encoder row-major [K, n_out].  Any image size.  Results equal gwbp_encode_map + gwbp_blend_scatter bit for
+ * bit in the encoded pixels, hence in every weight and (up to summation order) in F and d. */
+int gwbp_blend_scatter_encoded(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                               const float *feats, int64_t fs_y, int64_t fs_x, int32_t K, const float *encoder, int32_t n_out,
+                               float scale_f, float scale_d, float *F, float *d, float *alphas, void *stream);
+
 /* d[g] += scale_d * sum_p w_g(p) alone, from the per-record weight sums gwbp_blend_weights left in the workspace
  * (needs a blend WITHOUT GWBP_FLAG_NARROW_SCATTER).  A caller that overlaps the front stage of view v+1 with the
  * scatter of view v issues it behind the blend on the front's stream and passes d = NULL to gwbp_scatter: the

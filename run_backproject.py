@@ -37,8 +37,8 @@ def main():
                     help="ONE sweep instead of two: build the field on all Gaussians and take the mask from the same "
                          "denominators (keep = d > 0), then drop the pruned rows.  Not the reference's arithmetic to the last "
                          "digit: a pruned Gaussian has no weight anywhere but may be the one that TERMINATES pixels "
-                         "(T' <= 1e-4), so building with it present moves a few kept rows (C1: median 0, 99 % of the rows "
-                         "within 2e-3 of the prune-first result, tests/test_gpu_cli.py)")
+                         "(T' <= 1e-4), so building with it present moves some kept rows (C2 size, two views: median 7e-9, "
+                         "99 % of the rows within 1.2e-7, 0.4 % beyond 1e-3 of the prune-first result; tests/test_gpu_pruning.py)")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend under torchrun (nccl = RCCL over xGMI)")
     ap.add_argument("--one-device", action="store_true",
                     help="every rank uses cuda:0 (with --dist-backend gloo: the N > 1 bookkeeping on a one-GPU box)")

@@ -804,6 +804,53 @@ def test_scatter_encoded_matches_scatter_of_encoded_map(orc, dev, K, n):
     assert rel_row_err(res[0][1].cpu().numpy()[:, None], dr[:, None]) <= TOL
 
 
+@pytest.mark.parametrize("name,K,n", [("T1", 512, 16), ("T1", 64, 5), ("T0", 32, 16), ("C1", 128, 16)])
+def test_blend_scatter_encoded_matches_encode_then_blend_scatter(orc, dev, name, K, n):
+    """gwbp_blend_scatter_encoded (round 5: the 512 -> 16 encoder of backproject_compressed.py:127 inside the fused blend +
+    scatter kernel's tile prologue, on the matrix cores) against gwbp_encode_map + gwbp_blend_scatter of the same view -- the
+    encoded pixels are the same k-ordered fp32 chain, so the weights are equal and F, d differ by summation order only -- and
+    against the oracle fed the CPU-encoded map.  Edge tiles (image size not a multiple of 16), fewer than 16 outputs, a
+    pixel-strided map; the alpha maps must be equal bit for bit."""
+    cfg, sc = scene_np(name)
+    d, h = to_dev(sc, dev), npy(sc)
+    g = torch.Generator().manual_seed(K + n)
+    feats = torch.randn(cfg.height, cfg.width, K, generator=g)
+    enc = torch.randn(K, n, generator=g) / K ** 0.5
+    N = cfg.n_gaussians
+    eng = gsbp_amd.Engine(N, cfg.width, cfg.height, device=dev)
+    view = eng.view(d["vms"][0], d["K"], cfg.width, cfg.height)
+
+    def front():
+        eng.project(view, d["means"], d["quats"], d["scales"], d["opac"])
+        eng.bin_sort(view)
+
+    big = torch.zeros(cfg.height, cfg.width + 2, K + 16, device=dev)
+    big[:, :cfg.width, :K] = feats.to(dev)
+    res = []
+    for fmap in (feats.to(dev), big[:, :cfg.width, :K]):
+        F, dd = torch.zeros(N, n, device=dev), torch.zeros(N, device=dev)
+        front()
+        alphas = eng.blend_scatter_encoded(view, fmap, enc.to(dev), F, dd, want_alphas=True)
+        assert eng.stats()["overflow"] == 0
+        res.append((F, dd, alphas))
+    scale = float(res[0][0].norm(dim=1).max())
+    assert float((res[0][0] - res[1][0]).norm(dim=1).max()) <= 2e-5 * scale and torch.equal(res[0][2], res[1][2])
+    F2, d2 = torch.zeros(N, n, device=dev), torch.zeros(N, device=dev)
+    front()
+    a2 = eng.blend_scatter(view, eng.encode_map(feats.to(dev), enc.to(dev)), F2, d2, want_alphas=True)
+    assert torch.equal(res[0][2], a2)
+    assert float((res[0][0] - F2).norm(dim=1).max()) <= 2e-5 * scale
+    assert float((res[0][1] - d2).abs().max()) <= 2e-5 * float(d2.max())
+    Fr, dr = np.zeros((N, n), np.float64), np.zeros(N, np.float64)
+    orc.backproject_view(h["means"], h["quats"], h["scales"], h["opac"], h["vms"][0], h["K"], cfg.width, cfg.height,
+                         (feats @ enc).numpy(), Fr, dr)
+    assert rel_row_err(res[0][0].cpu().numpy(), Fr) <= TOL
+    assert rel_row_err(res[0][1].cpu().numpy()[:, None], dr[:, None]) <= TOL
+    with pytest.raises(gsbp_amd.GwbpError):  # K beyond the 32 KB the encoder may take in LDS
+        eng.blend_scatter_encoded(view, torch.zeros(cfg.height, cfg.width, 1024, device=dev), torch.zeros(1024, 16, device=dev),
+                                  torch.zeros(N, 16, device=dev), None)
+
+
 def test_c_abi_refuses_wide_scatter_of_a_narrow_blend_and_leaves_f_and_d_untouched(dev):
     """include/gwbp.h, gwbp_stats.overflow bit 2: gwbp_scatter asked for the 256-channel kernel (D % 256 == 0, no
     GWBP_FLAG_NARROW_SCATTER) on a view that was blended WITH the flag finds no weight sums in the headers: the call raises bit 2
