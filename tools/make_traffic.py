@@ -33,7 +33,8 @@ def config_entry(cfg):
     cands = [k for k in avg if "k_scatter" in k]
     bl = next((k for k in avg if "k_blend" in k), None)
     # (maps of at most 16 channels: blend and scatter are ONE kernel, gwbp_blend_scatter = k_blend<2>)
-    fused = next((k for k in avg if "k_blend<2>" in k), None)
+    # (round 5: with an encoder the same kernel also encodes, gwbp_blend_scatter_encoded = k_blend<3, 8>)
+    fused = next((k for k in avg if "k_blend<3" in k), None) or next((k for k in avg if "k_blend<2" in k), None)
     sc = fused or (max(cands, key=lambda k: avg[k].get("FETCH_SIZE", 0.0)) if cands else bl)
     bl = fused or bl
     a = avg.get(sc, {})
