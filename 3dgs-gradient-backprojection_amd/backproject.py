@@ -186,6 +186,8 @@ class ViewPipeline:
             for e, st in zip(self.eng, self.sides):
                 e.bind_stream(st)
             self.ev_ready = [torch.cuda.Event() for _ in range(K)]
+        self.ev_slot = [torch.cuda.Event() for _ in range(K)]  # view-per-stream schedule: "the view in this slot is done"
+        self.slot_used = [False] * K
         self.i_front = 0    # views whose front stage has been enqueued
         self.i_scatter = 0  # views whose scatter stage has been enqueued
         self.pending = {}
@@ -292,6 +294,8 @@ class ViewPipeline:
             if after is not None:
                 side.wait_event(after)
             self._scatter_on(side, b, feats, F, d, scale_f, scale_d, t0, t1, upsample, encoder)  # engine bound to `side`
+            self.ev_slot[b].record(side)
+            self.slot_used[b] = True
             self.i_scatter += 1
             return
         if after is not None:
@@ -323,6 +327,20 @@ class ViewPipeline:
         if t1 is not None:
             t1.record(main)
         e.accumulate_stats(self.accums[b if self.independent else 0])
+
+    def wait_for_slot(self) -> None:
+        """View-per-stream schedule: block the HOST until the view that last used the next scatter's slot is done, i.e. keep the
+        host at most K views ahead of the device.  Call it before producing a view's feature map.  Without it nothing
+        throttles the host there (a view's kernels wait for nothing the host waits for), and a feature function that
+        allocates a fresh map per view -- 3.47 GB at C2 size -- runs the caching allocator into the ground: a map handed to a
+        side stream is only recycled once that stream has passed it, so the host allocates dozens of maps before the first is
+        free again, and the allocator's out-of-memory path (synchronise, release, retry) then stalls the job for seconds
+        (the CLI at C5 size: 1.1 s or 6 s for the same command).  No-op in the other schedules: there the maps are
+        consumed on the caller's stream and recycled in stream order."""
+        if self.independent:
+            b = self.i_scatter % len(self.eng)
+            if self.slot_used[b]:
+                self.ev_slot[b].synchronize()
 
     def scatter_stream(self) -> torch.cuda.Stream:
         """The stream the NEXT scatter() runs on (the caller's current stream unless a view runs on a stream of its own)."""
@@ -515,6 +533,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                         probe = pipe.stats_async()
                     if i + pipe.lookahead < len(my_views):
                         pipe.front(views[i + pipe.lookahead], means, quats, scales, opacities, d, sd)
+                    pipe.wait_for_slot()  # (view-per-stream schedule only: the host stays at most `depth` maps ahead)
                     if enc_blend:
                         # encoder + blend + scatter of the view in one kernel, on the view's own stream
                         feats = first_map if i == 0 else feature_fn(v)
