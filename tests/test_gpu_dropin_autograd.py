@@ -60,7 +60,7 @@ def test_one_call_with_two_cameras_harvests_both(dev):
     f0, f1 = (syn.make_feature_map(cfg, v, dim=D).to(dev) for v in (0, 1))
     out, alphas, _ = rasterization(d["means"], d["quats"], d["scales"], d["opac"], t, d["vms"][:2], d["K"][None].expand(2, 3, 3),
                                    width=W, height=H, want_meta=False)
-    assert out.shape == (2, H, W, D) and alphas.shape == (2, H, W, 1) and float(out.abs().max()) == 0.0
+    assert out.shape == (2, H, W, D) and alphas.shape == (2, H, W, 1) and float(out.detach().abs().max()) == 0.0
     ((out[0] * f0).sum() + (out[1] * f1).sum()).backward()
     want = _explicit(dev, cfg, d, 0, f0).astype(np.float64) + _explicit(dev, cfg, d, 1, f1)
     assert rel_row_err(t.grad.cpu().numpy(), want) <= TOL
@@ -112,7 +112,7 @@ def test_a_table_rewritten_through_data_is_not_rendered_as_zero(dev):
     args = (d["means"], d["quats"], d["scales"], d["opac"])
     t = torch.zeros(N, 8, device=dev, requires_grad=True)
     out, _, _ = rasterization(*args, t, d["vms"][0][None], d["K"][None], width=W, height=H, want_meta=False)
-    assert float(out.abs().max()) == 0.0
+    assert float(out.detach().abs().max()) == 0.0
     t.data.copy_(torch.rand(N, 8, device=dev))
     out, alpha, _ = rasterization(*args, t, d["vms"][0][None], d["K"][None], width=W, height=H, want_meta=False)
     with torch.no_grad():
@@ -122,4 +122,4 @@ def test_a_table_rewritten_through_data_is_not_rendered_as_zero(dev):
     t.data.zero_()
     rz.invalidate_zero_table_cache()
     out, _, _ = rasterization(*args, t, d["vms"][0][None], d["K"][None], width=W, height=H, want_meta=False)
-    assert float(out.abs().max()) == 0.0
+    assert float(out.detach().abs().max()) == 0.0

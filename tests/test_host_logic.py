@@ -296,3 +296,18 @@ def test_zero_table_verdict_is_rechecked_on_a_sample_and_can_be_invalidated():
     t.data[1, 0] = 3.0               # one row outside the sample: needs the explicit invalidation
     rz.invalidate_zero_table_cache()
     assert not rz._is_zero_table(t)
+
+
+def test_view_pipeline_refuses_to_run_on_shared_hardware_queues(monkeypatch):
+    """GPU_MAX_HW_QUEUES was set by bench.py only, so the product CLI and library callers ran the pipeline on the
+    runtime's default 4 queues.  The package now asks for 8 when it is imported; if that came too late (runtime already up) or
+    the caller asked for fewer, ViewPipeline says so instead of silently running front + scatter back to back."""
+    from gsbp_amd import _lib
+    assert os.environ.get("GPU_MAX_HW_QUEUES") is not None and _lib.hw_queues_ok()
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    assert not _lib.hw_queues_ok()
+    with pytest.raises(gsbp_amd.GwbpError, match="GPU_MAX_HW_QUEUES"):
+        gsbp_amd.ViewPipeline(100, 64, 48, "cpu")
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    monkeypatch.setattr(_lib, "_QUEUES_LATE", True)  # the runtime was up before the package could ask
+    assert not _lib.hw_queues_ok()
