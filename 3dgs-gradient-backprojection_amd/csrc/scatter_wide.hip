@@ -20,8 +20,9 @@
 // Round 4 rewrite of the visit machinery (the arithmetic and the order of every record's sum are unchanged):
 //   * The pass's visit list is built BY THIS KERNEL, in LDS, from the blend's 64-B record headers while the slab loads are
 //     in flight (thread i takes record i, a ballot compacts the records that have entries in this half): the blend no
-//     longer writes half-tile lists, and a visit's descriptor is one broadcast ds_read_b128 -- no scalar loads in the
-//     loop, so every lgkmcnt wait of the batch loop is a counted one.
+//     longer writes half-tile lists, and a visit's descriptor is one broadcast ds_read_b96 (a scalar load of it would have forced
+//     every lgkmcnt wait of the loop to zero; the ONE scalar load per batch that round 5 put into the loop is accounted for
+//     in the batch's counted waits, see GWBP_BATCH_ASM).
 //   * Claims are asynchronous: the ds_add_rtn for the visit after next is issued at the top of a visit and read after its
 //     first batch; the descriptor read it enables completes under the rest of the visit.
 //   * Every VMEM operation of a visit addresses SGPR base + one of two per-lane constants (lane * 4 / 8): no vector
@@ -274,9 +275,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
             atomicOr(&ctr->overflow, kOverflowMismatch);
         return;
     }
-    // REGISTER BUDGET, deliberately padded.  The kernel needs 75 vector registers; naming v103 makes the hardware allocate 104
-    // per lane to each of its four waves per SIMD, which leaves 96: ONE 64-register wave of the front-stage kernels (k_blend,
-    // k_radix_scatter) per SIMD beside it.  Measured on one box (C2, three workspaces), allocation -> ms per view:
+    // REGISTER BUDGET, deliberately padded.  The kernel needs ~72 vector registers of its own; the batch buffer v[72:103] of the
+    // scalar-fed loop (and, for builds without it, naming v103 here) makes the hardware allocate 104 per lane to each of its
+    // four waves per SIMD, which leaves 96: ONE 64-register wave of the front-stage kernels (k_blend, k_radix_scatter) per
+    // SIMD beside it.  Measured on one box (C2, three workspaces), allocation -> ms per view:
     // 80 (three front waves per SIMD) 3.74, 88 / 96 (two) 3.72, 104 (one) 3.64, 112 (one) 3.67, 120 (none: the front's
     // kernels wait for the scatter kernel to END) 3.97.  More front waves beside the kernel cost it more than they gain.
     // tests/test_capi_cpu.py pins the allocation.
