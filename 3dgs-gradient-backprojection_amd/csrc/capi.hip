@@ -220,9 +220,9 @@ extern "C" {
 const char *gwbp_version(void)
 {
 #ifdef GWBP_PROFILE
-    return "libgwbp gfx950 r4 (PROFILE build: ablation knobs live, results may be invalid)";
+    return "libgwbp gfx950 r5 (PROFILE build: ablation knobs live, results may be invalid)";
 #else
-    return "libgwbp gfx950 r4";
+    return "libgwbp gfx950 r5";
 #endif
 }
 const char *gwbp_last_error_string(void) { return g_err; }
