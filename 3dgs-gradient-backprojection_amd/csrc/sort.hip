@@ -29,10 +29,15 @@ __global__ __launch_bounds__(kSortThreads) void k_hist(const u32 *__restrict__ k
     front_priority(prio);
     const u32 n = n_dev ? *n_dev : n_host;
     const u32 base = blockIdx.x * (u32)kSortItems;
+    // The level-2 passes are launched for the caller's CAPACITY (the intersection count lives on the device): a block beyond
+    // the data leaves at once, without touching the histogram -- k_scan stops at the last block that has data (round 5: the
+    // capacity is 16 N, 4-7 x the data; idle blocks used to write 256 zeros each and k_scan to scan them, 78 us per pass at C4)
+    if (base >= n)
+        return;
     __shared__ u32 s_h[256];
     s_h[threadIdx.x] = 0;
     __syncthreads();
-    if (base < n) {
+    {
 #pragma unroll 4
         for (int it = 0; it < kItemsPerThread; ++it) {
             const u32 idx = base + it * kSortThreads + threadIdx.x;
@@ -44,11 +49,14 @@ __global__ __launch_bounds__(kSortThreads) void k_hist(const u32 *__restrict__ k
     hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_h[threadIdx.x];
 }
 
-// block d: exclusive scan of hist[d][0..nblk) in place, digit_total[d] = sum
-__global__ __launch_bounds__(256) void k_scan(int nblk, u32 *__restrict__ hist, u32 *__restrict__ digit_total, int prio)
+// block d: exclusive scan of hist[d][0..nact) in place, digit_total[d] = sum; nact = the blocks that hold data
+__global__ __launch_bounds__(256) void k_scan(int nblk_all, const u32 *__restrict__ n_dev, u32 n_host, u32 *__restrict__ hist,
+                                              u32 *__restrict__ digit_total, int prio)
 {
     front_priority(prio);
-    u32 *row = hist + (size_t)blockIdx.x * nblk;
+    u32 *row = hist + (size_t)blockIdx.x * nblk_all; // (the row pitch stays the capacity's)
+    const u32 n = n_dev ? *n_dev : n_host;
+    const int nblk = (int)min((u32)nblk_all, (n + (u32)kSortItems - 1u) / (u32)kSortItems);
     __shared__ u32 s_wave[4];
     __shared__ u32 s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -452,7 +460,7 @@ static void radix_passes(const Ws &W, u32 *const keys[2], u32 *const vals[2], co
     for (int p = 0; p < passes; ++p) {
         const int in = p & 1, out = in ^ 1;
         hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(kSortThreads), 0, s, keys[in], n_dev, n_host, p * 8, nblk, W.hist, prio);
-        hipLaunchKernelGGL(k_scan, dim3(256), dim3(256), 0, s, nblk, W.hist, W.digit_total, prio);
+        hipLaunchKernelGGL(k_scan, dim3(256), dim3(256), 0, s, nblk, n_dev, n_host, W.hist, W.digit_total, prio);
         hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(kSortThreads), 0, s, keys[in], vals[in], keys[out],
                            vals[out], n_dev, n_host, p * 8, nblk, W.hist, W.digit_total, prio);
     }
