@@ -102,7 +102,9 @@ def _grad_is_unobserved(leaf: torch.Tensor, node) -> bool:
         return False
     try:
         return bool(torch._C._will_engine_execute_node(node))
-    except RuntimeError:  # "... we are currently running autograd.grad()"
+    except (RuntimeError, AttributeError, TypeError):
+        # RuntimeError: "... we are currently running autograd.grad()".  The query is a private torch API: if a release
+        # renames or re-types it, fall back to the returned-gradient path (always correct, one temporary per view slower).
         return False
 
 
