@@ -349,6 +349,30 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             }
         }
     }
+    // A non-finite feature value (backproject.py:109: feats / feats.norm() of an all-zero pixel is NaN) must reach exactly the
+    // Gaussians that have a weight AT that pixel -- the reference's backward adds fac * v_render for contributing pairs only.
+    // The record sums below multiply a lane's pixels by a weight that is 0 where the record has no entry, and 0 x NaN is NaN,
+    // which poisoned every record of the tile (found in round 5; the vector scatter kernels had been fixed in round 3).
+    // Once per tile: bad[q] = lanes whose pixel of quarter q holds a non-finite value (scalar masks), those pixels are zeroed
+    // in the registers, and a record whose entry mask meets bad[] gets NaN sums instead -- a few scalar instructions per
+    // record, no vector work in tiles without such pixels.  (All channels of the record become NaN, also where the reference
+    // would keep a finite or infinite one: the row is non-finite either way, and backproject.py:166-169 maps it to zeros.)
+    u64 bad[4] = {0ull, 0ull, 0ull, 0ull};
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float chk = 0.f;
+#pragma unroll
+            for (int c = 0; c < kFusedCh; ++c)
+                chk = __builtin_fmaf(f[q][c], 0.f, chk); // NaN iff some value is NaN or +-inf
+            bad[q] = __ballot(chk != chk);
+            if (bad[q] != 0ull) { // (wave-uniform, rare)
+#pragma unroll
+                for (int c = 0; c < kFusedCh; ++c)
+                    f[q][c] = (chk != chk) ? 0.f : f[q][c];
+            }
+        }
+    }
     // per-lane constants of the record flush: lanes 0..15 add channel transposed_channel(lane) of F[gid], lane 16 adds d[gid]
     const int my_ch = transposed_channel(lane);
     float *out_base = nullptr;
@@ -481,7 +505,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
                         for (int c = 0; c < kFusedCh; ++c)
                             p[c] = __builtin_fmaf(wq, f[q][c], p[c]);
                     }
-                const float tot = transposed_sum16(p); // every row: channel my_ch
+                float tot = transposed_sum16(p); // every row: channel my_ch
+                if (((m[0] & bad[0]) | (m[1] & bad[1]) | (m[2] & bad[2]) | (m[3] & bad[3])) != 0ull) // (scalar; see bad[] above)
+                    tot = __builtin_nanf("");
                 wl += dpp_get<0xB1>(wl);
                 wl += dpp_get<0x4E>(wl);
                 wl += dpp_get<0x141>(wl);
@@ -632,6 +658,19 @@ __global__ __launch_bounds__(64) void k_blend_scatter_quarter(ViewDev V, const u
                 f[c] = c < fu.D ? src[c] : 0.f;
         }
     }
+    u64 bad = 0ull; // lanes whose pixel holds a non-finite value: zeroed here, NaN for the records that touch them (see k_blend)
+    {
+        float chk = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            chk = __builtin_fmaf(f[c], 0.f, chk);
+        bad = __ballot(chk != chk);
+        if (bad != 0ull) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                f[c] = (chk != chk) ? 0.f : f[c];
+        }
+    }
     // flush: lanes 16 g .. 16 g + 15 add channels 16 g + transposed_channel(lane) of F[gid], lane CH adds d[gid]
     const int my_ch = 16 * (lane >> 4) + transposed_channel(lane);
     float *const out_base = lane < CH ? fu.F + my_ch : d_out;
@@ -692,7 +731,7 @@ __global__ __launch_bounds__(64) void k_blend_scatter_quarter(ViewDev V, const u
 #pragma unroll
             for (int c = 0; c < 16; ++c)
                 p0[c] = wq * f[c];
-            const float tot0 = transposed_sum16(p0);
+            float tot0 = transposed_sum16(p0);
             if constexpr (CH == 32) {
                 float p1[16];
 #pragma unroll
@@ -700,6 +739,8 @@ __global__ __launch_bounds__(64) void k_blend_scatter_quarter(ViewDev V, const u
                     p1[c] = wq * f[16 + c];
                 tot1 = transposed_sum16(p1);
             }
+            if ((m_valid & bad) != 0ull)
+                tot0 = tot1 = __builtin_nanf("");
             float wl = wq;
             wl += dpp_get<0xB1>(wl);
             wl += dpp_get<0x4E>(wl);

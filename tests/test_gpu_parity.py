@@ -933,3 +933,49 @@ def test_dropin_denominator_pass_from_the_weight_sums(orc, dev):
     assert dr.max() > 0
     assert rel_row_err(got.cpu().numpy(), Fr) <= TOL
     assert rel_row_err(got[:, :1].cpu().numpy() / 2.5, dr[:, None]) <= TOL
+
+
+def _nonfinite_case(orc, dev, name, D, fused, enc_k=None):
+    """One view, a feature map with a NaN pixel and a +inf pixel: NaN must reach exactly the Gaussians that have a weight at one
+    of those pixels (the reference's backward adds fac * v_render only for contributing pairs), every other row must match the
+    oracle.  backproject.py:109 produces such pixels: feats / feats.norm() of an all-zero pixel."""
+    cfg, sc = scene_np(name)
+    d, h = to_dev(sc, dev), npy(sc)
+    N, W, H = cfg.n_gaussians, cfg.width, cfg.height
+    g = torch.Generator().manual_seed(11)
+    K = enc_k or D
+    feats = torch.randn(H, W, K, generator=g)
+    feats[H // 2, W // 2, :] = float("nan")
+    feats[H // 3, W // 4, K // 2] = float("inf")
+    enc = torch.randn(K, D, generator=g) / K ** 0.5 if enc_k else None
+    eff = feats if enc is None else feats @ enc
+    Fr, dr = np.zeros((N, D), np.float64), np.zeros(N, np.float64)
+    orc.backproject_view(h["means"], h["quats"], h["scales"], h["opac"], h["vms"][0], h["K"], W, H, eff.numpy(), Fr, dr)
+    bad_ref = ~np.isfinite(Fr).all(axis=1)
+    assert 0 < bad_ref.sum() < N // 2
+    eng = gsbp_amd.Engine(N, W, H, device=dev)
+    view = eng.view(d["vms"][0], d["K"], W, H)
+    eng.project(view, d["means"], d["quats"], d["scales"], d["opac"])
+    eng.bin_sort(view)
+    F, dd = torch.zeros(N, D, device=dev), torch.zeros(N, device=dev)
+    if enc is not None:
+        eng.blend_scatter_encoded(view, feats.to(dev), enc.to(dev), F, dd)
+    elif fused:
+        eng.blend_scatter(view, feats.to(dev), F, dd)
+    else:
+        eng.blend_weights(view)
+        eng.scatter(view, feats.to(dev), F, dd)
+    Fh = F.cpu().numpy()
+    bad = ~np.isfinite(Fh).all(axis=1)
+    assert np.array_equal(bad, bad_ref), (int(bad.sum()), int(bad_ref.sum()))
+    assert rel_row_err(Fh[~bad], Fr[~bad]) <= TOL
+    assert rel_row_err(dd.cpu().numpy()[:, None], dr[:, None]) <= TOL
+
+
+@pytest.mark.parametrize("name,D,fused,enc_k", [("T1", 8, False, None), ("T1", 130, False, None), ("T1", 128, False, None),
+                                                ("T1", 256, False, None), ("T1", 16, True, None), ("T1", 5, True, None),
+                                                ("C1", 32, True, None), ("T1", 16, False, 64)],
+                         ids=["small_D8", "general_D130", "narrow_D128", "wide_D256", "fused_D16", "fused_D5", "fused_quarter_D32",
+                              "fused_encoder_64to16"])
+def test_non_finite_features_reach_exactly_the_gaussians_that_touch_them(orc, dev, name, D, fused, enc_k):
+    _nonfinite_case(orc, dev, name, D, fused, enc_k)
