@@ -21,6 +21,7 @@ orc.build()
 DIMS = [1, 3, 4, 7, 8, 12, 16, 17, 32, 40, 64, 65, 100, 128, 130, 256, 384, 512, 768]
 bad = 0
 n_fused = 0
+n_enc = 0
 t0 = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
@@ -56,23 +57,38 @@ for case in range(n_cases):
         if D < 4:
             feats = feats.abs()
     layout = rng.choice(["hwc", "chw", "pad"])
-    fd = (low if up is not None else feats).to(dev)
+    # the compressed variant in one kernel (round 5): a K-channel map and a [K, D] encoder, D <= 16; the oracle gets feats_in @ enc
+    enc = None
+    if up is None and D <= 16 and rng.random() < 0.4:
+        Kin = int(rng.choice([16, 32, 48, 64, 128, 512]))
+        feats_in = torch.randn(H, W, Kin, generator=g)
+        enc = torch.randn(Kin, D, generator=g) / Kin ** 0.5
+        if D < 4:  # (as for plain maps: rows of one to three signed values cancel and the relative row error means nothing)
+            feats_in, enc = feats_in.abs(), enc.abs()
+        feats = feats_in @ enc
+        layout = "pad" if layout == "chw" else layout  # (channel-contiguous pixels required)
+    fd = (low if up is not None else (feats if enc is None else feats_in)).to(dev)
     if layout == "chw":
         fd = fd.permute(2, 0, 1).contiguous().permute(1, 2, 0)
     elif layout == "pad":
-        buf = torch.zeros(fd.shape[0], fd.shape[1] + 2, D + 4, device=dev)
-        buf[:, :fd.shape[1], :D] = fd
-        fd = buf[:, :fd.shape[1], :D]
+        Dm = fd.shape[2]
+        buf = torch.zeros(fd.shape[0], fd.shape[1] + 2, Dm + 4, device=dev)
+        buf[:, :fd.shape[1], :Dm] = fd
+        fd = buf[:, :fd.shape[1], :Dm]
     wide = bool(rng.integers(0, 2))
     tight = bool(rng.integers(0, 2))
     eng = gsbp_amd.Engine(n, W, H, device=dev, tight_binning=tight, isect_cap=1 << 21, pair_cap=1 << 24)
     eng.set_narrow_scatter(not wide)
     view = eng.view(vm, K, W, H)
-    fused = up is None and bool(rng.integers(0, 2)) and gsbp_amd.Engine.can_blend_scatter(fd)
+    fused = enc is None and up is None and bool(rng.integers(0, 2)) and gsbp_amd.Engine.can_blend_scatter(fd)
     for attempt in range(4):  # a capacity overflow invalidates the view: grow the workspace and run it again
         F = torch.zeros(n, D, device=dev)
         d = torch.zeros(n, device=dev)
-        if fused:  # D <= 16, unit channel stride: blend + scatter in one kernel (gwbp_blend_scatter)
+        if enc is not None:  # encoder + blend + scatter in one kernel (gwbp_blend_scatter_encoded)
+            eng.project(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
+            eng.bin_sort(view)
+            eng.blend_scatter_encoded(view, fd, enc.to(dev), F, d)
+        elif fused:  # D <= 16, unit channel stride: blend + scatter in one kernel (gwbp_blend_scatter)
             eng.project(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
             eng.bin_sort(view)
             eng.blend_scatter(view, fd, F, d)
@@ -88,6 +104,7 @@ for case in range(n_cases):
         eng.grow(eng.stats())
         eng.set_narrow_scatter(not wide)
     n_fused += int(fused)
+    n_enc += int(enc is not None)
     st = eng.stats()
     Fr, dr = np.zeros((n, D), np.float64), np.zeros(n, np.float64)
     info = orc.backproject_view(means.numpy(), quats.numpy(), scales.numpy(), opac.numpy(), vm.numpy(), K.numpy(), W, H,
@@ -98,7 +115,8 @@ for case in range(n_cases):
     ok = ok and eF <= 1e-4 and ed <= 1e-4 and (tight or st["n_isect"] == info["n_isect"])
     if not ok:
         bad += 1
-        print(f"FAIL case {seed0 + case}: N={n} {W}x{H} D={D} s0={s0:.4f} {layout} up={up} wide={wide} tight={tight} fused={fused} "
+        print(f"FAIL case {seed0 + case}: N={n} {W}x{H} D={D} s0={s0:.4f} {layout} up={up} wide={wide} tight={tight} fused={fused} enc={None if enc is None else tuple(enc.shape)} "
               f"pairs {st['n_pairs']}/{info['n_pairs']} eF={eF:.2e} ed={ed:.2e} overflow={st['overflow']}", flush=True)
-print(f"{n_cases} cases ({n_fused} through the fused blend+scatter kernel), {bad} failures, {time.time() - t0:.0f} s")
+print(f"{n_cases} cases ({n_fused} through the fused blend+scatter kernel, {n_enc} through the encoder-fused one), {bad} failures, "
+      f"{time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
