@@ -250,10 +250,13 @@ __device__ __forceinline__ u32 mbcnt(u64 mask)
 // GWBP_FLAG_FRONT_PRIORITY: the front-stage kernels (project / sort / blend of view v+1) raise their waves' issue
 // priority.  Beside the persistent scatter kernel of view v the SIMD arbiter otherwise serves the four older scatter waves
 // first and the front's dependent instruction chains stretch 3x (k_blend 1.0 -> 2.9 ms at equal occupancy).
+#ifndef GWBP_FRONT_PRIO
+#define GWBP_FRONT_PRIO 3 // (levels 1, 2 and 3 measured equal at C2, round 5: 3.43-3.45 ms/view each; 0 = off costs 4 %)
+#endif
 __device__ __forceinline__ void front_priority(int on)
 {
     if (on)
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(GWBP_FRONT_PRIO);
 }
 // Sum over the 64 lanes, returned wave-uniform: four DPP adds inside each row of 16 lanes, then the four row totals.
 template <int CTRL>
