@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import gsbp_amd  # noqa: E402,F401  (first thing in the test process: the package asks the HIP runtime for the hardware queues its view
+                 # pipeline needs, which only works before the first HIP call)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
