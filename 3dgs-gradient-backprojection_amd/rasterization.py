@@ -165,7 +165,7 @@ def _run_front(eng: Engine, view, means, quats, scales, opacities, want_alphas, 
 
 class _Rasterize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, colors, means, quats, scales, opacities, viewmat, K, width, height, kw, holder):
+    def forward(ctx, colors, means, quats, scales, opacities, viewmat, K, width, height, kw, holder, harvest=None):
         dev = means.device
         eng = get_engine(dev, means.shape[0], width, height)
         view = eng.view(viewmat, K, width, height, **kw)
@@ -176,7 +176,8 @@ class _Rasterize(torch.autograd.Function):
         eng.set_narrow_scatter(not (colors.requires_grad and D % 256 == 0))
         # the reference's harvesting pattern: an all-zero differentiable colour table whose render is only there to be
         # back-propagated through (backproject.py:67-72,115-129,133-147) -- the render of zeros is zeros, for any D
-        harvest = colors.requires_grad and _is_zero_table(colors)
+        if harvest is None:
+            harvest = colors.requires_grad and _is_zero_table(colors)
         proj, bins, alphas, st = _run_front(eng, view, means, quats, scales, opacities, D > 4 or harvest,
                                             holder is not None, want_store=need_store)
         if harvest:
@@ -222,10 +223,10 @@ class _Rasterize(torch.autograd.Function):
                 and _grad_is_unobserved(leaf, ctx.leaf_node)):
             _scatter_grad(eng, view, g_out, acc)
             acc[:0].add_(0)  # the kernel wrote through data_ptr: move .grad's version counter like an in-place op would
-            return (None,) * 11
+            return (None,) * 12
         v_colors = torch.zeros(ctx.shape, device=means.device, dtype=torch.float32)
         _scatter_grad(eng, view, g_out, v_colors)
-        return (v_colors,) + (None,) * 10
+        return (v_colors,) + (None,) * 11
 
 
 def _scatter_grad(eng: Engine, view, g_out: torch.Tensor, acc: torch.Tensor) -> None:
@@ -236,6 +237,107 @@ def _scatter_grad(eng: Engine, view, g_out: torch.Tensor, acc: torch.Tensor) -> 
         eng.scatter_uniform(view, g_out[0, 0, 0], acc)
     else:
         eng.scatter(view, g_out, acc, None)
+
+
+# ---- the harvest statement `(render[0] * feats).sum().backward()` without its three [H,W,D] passes --------------------------
+# backproject.py:127-129.  `render` is the render of an all-zero table, i.e. zeros: the product is zeros, its sum is 0, and
+# the gradient that reaches the rasteriser's backward is feats itself.  Run literally, torch spends 3.8 ms per C2 view on it
+# (multiply 1.8, sum 0.9, the multiply's backward 1.1: each a pass over 3.47 GB) -- more than the scatter kernel that does the
+# work.  The render of a harvest call is therefore handed out as a tensor SUBCLASS that recognises exactly this statement:
+#   render * feats   (either order, Tensor.mul too; same shape / dtype / device, feats a plain tensor without grad)
+#       -> _HarvestProduct: no kernel; its data ARE the zeros of the render
+#   product.sum() / product.mean()    (the full reductions: lseg backproject.py:127, dino :263)
+#       -> a scalar 0 whose backward hands `feats` (times the incoming scalar, read on the host: 1.0 for a plain
+#          .backward(); times 1 / numel for the mean) to the rasteriser's backward as the gradient of the render -- no copy
+#          when that factor is one, one scaled copy otherwise
+# EVERYTHING else -- any other operation on the render or on the product, a feats that requires grad, a broadcasting shape --
+# falls back to the literal computation (the product is materialised with torch.mul, history and all), so results never depend
+# on the shortcut.  One visible difference: with non-finite values in feats (backproject.py:109 can produce NaN pixels) the
+# literal `target` is NaN and this one is 0; nothing in the reference reads it, and the gradient -- NaN at exactly those pixels --
+# is the same.
+_HARVEST_SHORTCUT = True
+
+
+def set_harvest_shortcut(on: bool) -> None:
+    """Switch the recognition of `(render * feats).sum()` on harvest renders on (default) or off (every statement is then
+    computed literally by torch: 3.8 ms more per C2 view, same gradients)."""
+    global _HARVEST_SHORTCUT
+    _HARVEST_SHORTCUT = bool(on)
+
+
+def _plain(t: torch.Tensor) -> torch.Tensor:
+    return t.as_subclass(torch.Tensor) if type(t) is not torch.Tensor else t
+
+
+class _HarvestSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, render, feats, scale):
+        ctx.feats, ctx.scale = feats, scale
+        return render.new_zeros(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        k = float(g) * ctx.scale  # (a host read of one scalar; the loop's other statements synchronise anyway)
+        return (ctx.feats if k == 1.0 else ctx.feats * k), None, None
+
+
+_MUL_FUNCS = (torch.mul, torch.Tensor.mul, torch.Tensor.__mul__, torch.Tensor.__rmul__, torch.multiply, torch.Tensor.multiply)
+_SUM_FUNCS = (torch.sum, torch.Tensor.sum)
+_MEAN_FUNCS = (torch.mean, torch.Tensor.mean)  # (the dino variant, backproject.py:263: one scaled copy of feats instead of three passes)
+_META_PROPS = ("shape", "dtype", "device", "ndim", "layout", "is_cuda", "is_cpu", "is_sparse", "is_quantized", "is_meta", "names")
+_META_METHODS = ("size", "dim", "ndimension", "numel", "nelement", "stride", "element_size", "is_floating_point", "is_complex",
+                 "is_contiguous", "get_device", "__len__")
+
+
+class _HarvestProduct(torch.Tensor):
+    """`render * feats` of a harvest render, not computed (see above).  Any use other than the full `.sum()` materialises it."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        me = next((a for a in args if isinstance(a, _HarvestProduct)), None)
+        if ((func in _SUM_FUNCS or func in _MEAN_FUNCS) and me is not None and len(args) == 1 and not kwargs
+                and torch.is_grad_enabled() and getattr(me, "_harvest", None) is not None):
+            render, feats = me._harvest
+            return _HarvestSum.apply(_plain(render), feats, 1.0 if func in _SUM_FUNCS else 1.0 / max(1, feats.numel()))
+        # metadata never needs the data: properties (shape, dtype, device, ...) and the size-like methods answer from the
+        # placeholder; `requires_grad` answers what the literal product would
+        name = getattr(func, "__name__", "")
+        if name == "__get__":
+            prop = getattr(getattr(func, "__self__", None), "__name__", "")
+            if prop == "requires_grad":
+                return True
+            if prop in _META_PROPS:
+                with torch._C.DisableTorchFunctionSubclass():
+                    return func(*args, **kwargs)
+        elif name in _META_METHODS:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        with torch._C.DisableTorchFunctionSubclass():
+            def real(a):
+                if isinstance(a, _HarvestProduct) and getattr(a, "_harvest", None) is not None:
+                    return torch.mul(_plain(a._harvest[0]), a._harvest[1])  # the literal product, with its history
+                return _plain(a) if isinstance(a, torch.Tensor) else a
+            return func(*[real(a) for a in args], **{k: real(v) for k, v in kwargs.items()})
+
+
+class _HarvestRender(torch.Tensor):
+    """[H,W,D] render of an all-zero differentiable colour table (attached to the autograd graph like any output)."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _MUL_FUNCS and len(args) == 2 and not kwargs and torch.is_grad_enabled():
+            a, b = args
+            r, f = (a, b) if isinstance(a, _HarvestRender) else (b, a)
+            if (isinstance(r, _HarvestRender) and type(f) is torch.Tensor and r.requires_grad and not f.requires_grad
+                    and f.shape == r.shape and f.dtype == r.dtype and f.device == r.device):
+                p = _plain(r).detach().as_subclass(_HarvestProduct)  # (data: the render's zeros; no kernel)
+                p._harvest = (r, f)
+                return p
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
 
 
 class _OneCameraBatch(torch.Tensor):
@@ -354,8 +456,11 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         if need_depth:
             z = (means @ vm[:3, :3].T + vm[:3, 3])[:, 2:3]
             cols = z if render_mode in ("D", "ED") else torch.cat([cols, z], dim=1)
-        out, alpha = _Rasterize.apply(cols.contiguous(), means, quats, scales, opacities, vm, K, width, height, kw,
-                                      holder)
+        cols = cols.contiguous()
+        harvest = bool(cols.requires_grad and _is_zero_table(cols))
+        out, alpha = _Rasterize.apply(cols, means, quats, scales, opacities, vm, K, width, height, kw, holder, harvest)
+        if _HARVEST_SHORTCUT and harvest and render_mode == "RGB" and backgrounds is None and out.requires_grad:
+            out = out.as_subclass(_HarvestRender)  # recognises `(render * feats).sum()`, behaves like a tensor otherwise
         alpha = alpha[..., None]
         if render_mode in ("ED", "RGB+ED"):
             out = torch.cat([out[..., :-1], out[..., -1:] / alpha.clamp_min(1e-10)], dim=-1)

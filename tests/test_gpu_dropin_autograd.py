@@ -123,3 +123,39 @@ def test_a_table_rewritten_through_data_is_not_rendered_as_zero(dev):
     rz.invalidate_zero_table_cache()
     out, _, _ = rasterization(*args, t, d["vms"][0][None], d["K"][None], width=W, height=H, want_meta=False)
     assert float(out.detach().abs().max()) == 0.0
+
+
+def test_harvest_statement_shortcut_equals_the_literal_computation(dev):
+    """`(out[0] * feats).sum().backward()` on the render of an all-zero table (backproject.py:127-129) is recognised: no
+    product, no sum, no product gradient -- feats itself reaches the scatter.  Same gradient as with the recognition switched
+    off (torch computes every statement), as the dino variant's `.mean()` (recognised too: one scaled copy of feats) and a
+    partial reduction (NOT recognised: falls back to the literal computation), and as the explicit scatter."""
+    rz = sys.modules["gsbp_amd.rasterization"]
+    cfg, sc = scene_np("T1")
+    d = to_dev(sc, dev)
+    N, W, H, D = cfg.n_gaussians, cfg.width, cfg.height, 256
+    args = (d["means"], d["quats"], d["scales"], d["opac"])
+    f = syn.make_feature_map(cfg, 0, dim=D).to(dev)
+    want = _explicit(dev, cfg, d, 0, f)
+
+    def run(reduce):
+        t = torch.zeros(N, D, device=dev, requires_grad=True)
+        out, _, _ = rasterization(*args, t, d["vms"][0][None], d["K"][None], width=W, height=H, want_meta=False)
+        prod = out[0] * f
+        reduce(prod).backward()
+        return t.grad.cpu().numpy(), type(out[0]).__name__, type(prod).__name__
+
+    g_short, t_r, t_p = run(lambda p: p.sum())
+    assert (t_r, t_p) == ("_HarvestRender", "_HarvestProduct")
+    rz.set_harvest_shortcut(False)
+    try:
+        g_lit, t_r, t_p = run(lambda p: p.sum())
+    finally:
+        rz.set_harvest_shortcut(True)
+    assert (t_r, t_p) == ("Tensor", "Tensor")
+    g_mean, _, _ = run(lambda p: p.mean())
+    g_part, _, _ = run(lambda p: p.sum(dim=2).sum())
+    assert rel_row_err(g_part, want) <= TOL
+    assert rel_row_err(g_short, want) <= TOL and rel_row_err(g_lit, want) <= TOL
+    assert rel_row_err(g_short, g_lit) <= 2e-6
+    assert rel_row_err(g_mean * (H * W * D), want) <= TOL

@@ -311,3 +311,46 @@ def test_view_pipeline_refuses_to_run_on_shared_hardware_queues(monkeypatch):
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
     monkeypatch.setattr(_lib, "_QUEUES_LATE", True)  # the runtime was up before the package could ask
     assert not _lib.hw_queues_ok()
+
+
+def test_harvest_render_shortcut_and_its_fallbacks():
+    """The render of an all-zero differentiable table recognises the reference's harvest statement
+    `(render * feats).sum().backward()` (backproject.py:127-129) and hands feats to the rasteriser's backward without computing
+    the product, its sum or the product's gradient; every other use falls back to the literal computation.  CPU check of the
+    tensor subclasses against a toy render that is attached to a graph."""
+    import sys
+    rz = sys.modules["gsbp_amd.rasterization"]
+    leaf = torch.zeros(4, 5, 3, requires_grad=True)
+    f = torch.randn(4, 5, 3)
+
+    def render():
+        return (leaf * 1.0).as_subclass(rz._HarvestRender)
+
+    def grad_of(loss):
+        leaf.grad = None
+        loss.backward()
+        return leaf.grad.clone()
+
+    p = render() * f
+    assert type(p) is rz._HarvestProduct and p.shape == f.shape and p.requires_grad and p.numel() == f.numel()  # (metadata only: no kernel)
+    s = p.sum()
+    assert type(s) is torch.Tensor and "HarvestSum" in type(s.grad_fn).__name__ and float(s.detach()) == 0.0
+    assert torch.equal(grad_of(s), f)
+    assert torch.equal(grad_of((f * render()).sum()), f)                       # __rmul__
+    assert torch.allclose(grad_of(render().mul(f).sum() * 2.5), 2.5 * f)       # an incoming scalar other than one
+    m = (render() * f).mean()                                                  # the dino variant's .mean(), backproject.py:263
+    assert "HarvestSum" in type(m.grad_fn).__name__ and torch.allclose(grad_of(m), f / f.numel())
+    # fallbacks: the literal computation, same gradients
+    assert torch.allclose(grad_of((render() * f).mean(dim=(0, 1)).sum()), f / (f.shape[0] * f.shape[1]))
+    assert torch.allclose(grad_of((render() * f).sum(dim=0).sum()), f)
+    g = grad_of((render() * f)[..., :2].sum())
+    assert torch.equal(g[..., :2], f[..., :2]) and float(g[..., 2].abs().max()) == 0.0
+    fg = f.clone().requires_grad_(True)
+    assert torch.equal(grad_of((render() * fg).sum()), f) and float(fg.grad.abs().max()) == 0.0   # feats with grad: d/dfeats = render = 0
+    assert grad_of((render() * f[:, :, :1]).sum()).shape == leaf.shape         # broadcasting
+    assert type(render() + 1.0) is torch.Tensor and type(render()[None]) is torch.Tensor
+    with torch.no_grad():
+        assert type(render() * f) is torch.Tensor
+    # two statements on one render accumulate like any two uses
+    r = render()
+    assert torch.allclose(grad_of((r * f).sum() + (r * (2 * f)).sum()), 3 * f)
