@@ -362,21 +362,22 @@ __global__ __launch_bounds__(256) void k_tile_offsets(const u32 *__restrict__ ke
 {
     front_priority(prio);
     const u32 n = ctr->n_isect;
-    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    const u32 i0 = blockIdx.x * 256u + threadIdx.x;
     if (n == 0) {
-        for (u32 t = i; t <= (u32)n_tiles; t += gridDim.x * 256u)
+        for (u32 t = i0; t <= (u32)n_tiles; t += gridDim.x * 256u)
             offsets[t] = 0;
         return;
     }
-    if (i >= n)
-        return;
-    const int t = (int)keys[i];
-    const int tp = (i == 0) ? -1 : (int)keys[i - 1];
-    for (int tt = tp + 1; tt <= t; ++tt)
-        offsets[tt] = i;
-    if (i == n - 1)
-        for (int tt = t + 1; tt <= n_tiles; ++tt)
-            offsets[tt] = n;
+    // grid-stride over the DATA (the count lives on the device; a grid sized for the capacity was 312 K mostly idle blocks at C4)
+    for (u32 i = i0; i < n; i += gridDim.x * 256u) {
+        const int t = (int)keys[i];
+        const int tp = (i == 0) ? -1 : (int)keys[i - 1];
+        for (int tt = tp + 1; tt <= t; ++tt)
+            offsets[tt] = i;
+        if (i == n - 1)
+            for (int tt = t + 1; tt <= n_tiles; ++tt)
+                offsets[tt] = n;
+    }
 }
 
 // gsplat's meta: isect_ids = tile << 32 | depth bits (rebuilt from the tile key and the Gaussian's depth), flatten_ids
@@ -499,7 +500,7 @@ int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *ise
     radix_passes(W, W.keys, W.vals, &W.counters->n_isect, 0u, nblk2, passes, prio, s);
     const int fin = passes & 1;
     const int ob = (int)((L.isect_cap + 255) / 256);
-    hipLaunchKernelGGL(k_tile_offsets, dim3(ob > 0 ? ob : 1), dim3(256), 0, s, W.keys[fin], W.counters, n_tiles,
+    hipLaunchKernelGGL(k_tile_offsets, dim3(ob > 0 ? (ob < 4096 ? ob : 4096) : 1), dim3(256), 0, s, W.keys[fin], W.counters, n_tiles,
                        W.tile_offsets, prio);
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kOrderThreads), 0, s, W.tile_offsets, n_tiles, W.tile_order, prio);
     if (isect_ids || flatten_ids)
