@@ -160,10 +160,25 @@ __device__ __forceinline__ void load_u(u32 &dst, u32 voff, u64 base)
 {
     asm volatile("global_load_dword %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(base) : "memory");
 }
+// Wait for the two asm-issued loads of the next item's facts: everything but the wave's last flush (`few` != 0: the wave ran
+// visits and has at most that flush in flight) or everything.  ONE statement with a scalar branch inside: written as two
+// statements in an if / else, the two tied outputs met in a phi, and a build with in-kernel stamps (different register
+// allocation) resolved it with v_mov copies of the landing registers IN FRONT of the wait of one branch -- copies of
+// registers whose loads had not landed (found in round 5: waves without visits then read stale record counts; the product
+// build happened to place the copies behind the wait).
 template <int N>
-__device__ __forceinline__ void wait_info(u32 &a, u32 &b)
+__device__ __forceinline__ void wait_info(u32 few, u32 &a, u32 &b)
 {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+    asm volatile("s_cmp_lg_u32 %2, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_branch 2f\n"
+                 "1:\n\t"
+                 "s_waitcnt vmcnt(%3)\n"
+                 "2:"
+                 : "+v"(a), "+v"(b)
+                 : "s"(few), "n"(N)
+                 : "scc", "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_land(Land &x)
@@ -663,10 +678,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
     // complete (every visit waited for its own).
     GWBP_STAMP(ts2);
     // (a wave that ran visits has at most its last flush in flight; one that did not may have to wait for older atomics)
-    if (ran)
-        wait_info<kFlush>(nx_nrec, nx_toff);
-    else
-        wait_info<0>(nx_nrec, nx_toff);
+    wait_info<kFlush>(ran ? 1u : 0u, nx_nrec, nx_toff);
     GWBP_STAMP(ts3);
 #ifdef GWBP_STAMPS
     prof_acc[1] += ts2 - ts1, prof_acc[2] += ts3 - ts2;

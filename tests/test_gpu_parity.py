@@ -979,3 +979,19 @@ def _nonfinite_case(orc, dev, name, D, fused, enc_k=None):
                               "fused_encoder_64to16"])
 def test_non_finite_features_reach_exactly_the_gaussians_that_touch_them(orc, dev, name, D, fused, enc_k):
     _nonfinite_case(orc, dev, name, D, fused, enc_k)
+
+
+def test_profile_build_of_the_wide_kernel_agrees_with_the_narrow_one(dev):
+    """k_scatter_wide keeps asm-issued loads in flight across compiler-visible code; a build with a different register allocation
+    (PROFILE + in-kernel stamps) once copied two landing registers in front of their wait.  When the PROFILE library has been
+    built (make -C <pkg>/csrc PROFILE=1 -> tools/lib/libgwbp_profile.so), run the wide-vs-narrow comparison on it in a child
+    process (one library per process); skipped otherwise."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "tools", "lib", "libgwbp_profile.so")
+    if not os.path.exists(lib):
+        pytest.skip("PROFILE library not built")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "wide_vs_narrow.py"), lib], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
