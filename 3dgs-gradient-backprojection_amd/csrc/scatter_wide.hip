@@ -245,12 +245,21 @@ __device__ __forceinline__ void batch_prime(u64 first)
 }
 // one lane, one LDS atomic, NOT waited for (the wave-aggregation sequence hipcc wraps around a single-lane atomicAdd is ~8
 // instructions and waits at once)
+// (The lane mask is set INSIDE the statement: as `if (lane == 0) asm(...)` the tied output met its old value in a phi behind
+// the branch, which a differently allocated build may resolve with a copy of the register the atomic has not returned into yet
+// -- the hazard class of wait_info above.)
 __device__ __forceinline__ void claim_issue(u32 &dst, u32 addr, int lane)
 {
-    if (lane == 0) {
-        const u32 one = 1u;
-        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "+v"(dst) : "v"(addr), "v"(one) : "memory");
-    }
+    (void)lane;
+    const u32 one = 1u;
+    u64 saved;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "ds_add_rtn_u32 %0, %2, %3\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "+v"(dst), "=&s"(saved)
+                 : "v"(addr), "v"(one)
+                 : "memory");
 }
 typedef u32 u32x3_t __attribute__((ext_vector_type(3))); // a native vector: HIP's uint3 is a struct, not an asm operand
 // (12 of a table entry's 16 bytes: three registers in flight per wave instead of four -- see the note on lane8 below)
@@ -607,20 +616,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
                     // visit's own first batch once more -- a valid address, never consumed)
                     const u64 e_cur = entries_of(cur), e_nxt = entries_of(vnxt ? nxt : cur);
                     const u32 nb = (cur.n + 7u) >> 3;
+                    // the first batch stands outside the loop so that the descriptor read behind it is issued unconditionally
+                    // (inside `if (b == 0)` its tied output would meet the loop-carried value in a phi: the hazard class of
+                    // wait_info above)
+                    batch_run(par_s, nb > 1u ? e_cur + 64u : e_nxt, row_base, acc_lo, acc_hi);
+                    par_s ^= 1u;
+                    // the claim has returned with the first batch (its last FMA waited for lgkmcnt(0)): read its descriptor, which
+                    // lands under the second batch -- or is waited for below
+                    wait_lds(cl);
+                    h_n2 = uniform(cl);
+                    table_issue(tn, kTabOff + 16u * slot_of(min(h_n2, nv - 1u)));
 #pragma unroll 1
-                    for (u32 b = 0;;) {
+                    for (u32 b = 1; b < nb; ++b) {
                         const u64 next = (b + 1u < nb) ? e_cur + (u64)((b + 1u) << 6) : e_nxt;
                         batch_run(par_s, next, row_base, acc_lo, acc_hi);
                         par_s ^= 1u;
-                        if (b == 0) {
-                            // the claim has returned with the first batch (its last FMA waited for lgkmcnt(0)): read its descriptor,
-                            // which lands under the second batch -- or is waited for below
-                            wait_lds(cl);
-                            h_n2 = uniform(cl);
-                            table_issue(tn, kTabOff + 16u * slot_of(min(h_n2, nv - 1u)));
-                        }
-                        if (++b == nb)
-                            break;
                     }
                 } else {
                     wait_lds(cl);
