@@ -25,6 +25,12 @@ _QUEUES_LATE = "GPU_MAX_HW_QUEUES" not in os.environ and torch.cuda.is_initializ
 os.environ.setdefault("GPU_MAX_HW_QUEUES", str(HW_QUEUES_WANTED))
 
 
+def hw_queues_late() -> bool:
+    """The HIP runtime was already up when the package was imported, and nobody had set GPU_MAX_HW_QUEUES: the request for
+    HW_QUEUES_WANTED queues came too late to take effect."""
+    return _QUEUES_LATE
+
+
 def hw_queues_ok() -> bool:
     """False when the pipeline's streams may be sharing hardware queues: the HIP runtime started before this package could ask
     for HW_QUEUES_WANTED queues, or the caller asked for fewer."""

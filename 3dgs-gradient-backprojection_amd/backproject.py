@@ -131,7 +131,7 @@ class ViewPipeline:
                  view_per_stream: Optional[bool] = None):
         self.dev = torch.device(device)
         from . import _lib
-        if not _lib.hw_queues_ok():
+        if _lib.hw_queues_late():
             # the schedule below is built on streams that run CONCURRENTLY; with the HIP runtime's default of 4 hardware queues
             # (fewer once RCCL has taken its own) the side streams share a queue with the caller's and the step becomes front +
             # scatter.  The package asks for 8 when it is imported (_lib.py), which only works before the first HIP call.
@@ -139,6 +139,10 @@ class ViewPipeline:
                 "ViewPipeline needs GPU_MAX_HW_QUEUES >= %d, read by the HIP runtime when it starts: import gsbp_amd (or set "
                 "the variable) before the first CUDA/HIP call of the process, or run the views with pipeline=False"
                 % _lib.HW_QUEUES_WANTED)
+        if not _lib.hw_queues_ok():  # somebody CHOSE fewer queues (the variable was set before the package was imported)
+            import warnings
+            warnings.warn("GPU_MAX_HW_QUEUES=%s < %d: the view pipeline's streams may share hardware queues and run back to back"
+                          % (__import__("os").environ.get("GPU_MAX_HW_QUEUES"), _lib.HW_QUEUES_WANTED), RuntimeWarning)
         self.eng = list(engines) if engines else [Engine(n_gaussians, width, height, device=self.dev, tight_binning=True)
                                                   for _ in range(2)]
         # Scatter grid under overlap: one persistent workgroup per CU is the measured optimum once the front stage is

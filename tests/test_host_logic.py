@@ -304,13 +304,19 @@ def test_view_pipeline_refuses_to_run_on_shared_hardware_queues(monkeypatch):
     the caller asked for fewer, ViewPipeline says so instead of silently running front + scatter back to back."""
     from gsbp_amd import _lib
     assert os.environ.get("GPU_MAX_HW_QUEUES") is not None and _lib.hw_queues_ok()
-    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
-    assert not _lib.hw_queues_ok()
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    monkeypatch.setattr(_lib, "_QUEUES_LATE", True)  # the runtime was up before the package could ask: refuse
+    assert not _lib.hw_queues_ok() and _lib.hw_queues_late()
     with pytest.raises(gsbp_amd.GwbpError, match="GPU_MAX_HW_QUEUES"):
         gsbp_amd.ViewPipeline(100, 64, 48, "cpu")
-    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
-    monkeypatch.setattr(_lib, "_QUEUES_LATE", True)  # the runtime was up before the package could ask
-    assert not _lib.hw_queues_ok()
+    monkeypatch.setattr(_lib, "_QUEUES_LATE", False)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")     # somebody chose fewer: say so, do not refuse
+    assert not _lib.hw_queues_ok() and not _lib.hw_queues_late()
+    with pytest.warns(RuntimeWarning, match="GPU_MAX_HW_QUEUES"):
+        try:
+            gsbp_amd.ViewPipeline(100, 64, 48, "cpu")
+        except Exception:  # (no HIP device here: the engines behind the guard cannot be created)
+            pass
 
 
 def test_harvest_render_shortcut_and_its_fallbacks():
