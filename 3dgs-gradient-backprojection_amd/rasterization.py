@@ -15,6 +15,7 @@ import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
+from torch.utils import _pytree
 
 from ._lib import GwbpError
 from .engine import TILE, Engine
@@ -272,14 +273,16 @@ def _plain(t: torch.Tensor) -> torch.Tensor:
 class _HarvestSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, render, feats, scale):
-        ctx.feats, ctx.scale = feats, scale
+        ctx.save_for_backward(feats)  # (saved, not just referenced: an in-place write into feats between the statement and its
+        ctx.scale = scale             # backward raises, as it would for the literal product's saved operand)
         return render.new_zeros(())
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
+        (feats,) = ctx.saved_tensors
         k = float(g) * ctx.scale  # (a host read of one scalar; the loop's other statements synchronise anyway)
-        return (ctx.feats if k == 1.0 else ctx.feats * k), None, None
+        return (feats if k == 1.0 else feats * k), None, None
 
 
 _MUL_FUNCS = (torch.mul, torch.Tensor.mul, torch.Tensor.__mul__, torch.Tensor.__rmul__, torch.multiply, torch.Tensor.multiply)
@@ -319,7 +322,10 @@ class _HarvestProduct(torch.Tensor):
                 if isinstance(a, _HarvestProduct) and getattr(a, "_harvest", None) is not None:
                     return torch.mul(_plain(a._harvest[0]), a._harvest[1])  # the literal product, with its history
                 return _plain(a) if isinstance(a, torch.Tensor) else a
-            return func(*[real(a) for a in args], **{k: real(v) for k, v in kwargs.items()})
+            # (tree_map: the placeholder may sit inside a list or tuple argument -- torch.stack([p, q]), torch.cat -- where it
+            # must not be read as the detached zeros it physically is)
+            args, kwargs = _pytree.tree_map(real, (tuple(args), dict(kwargs)))
+            return func(*args, **kwargs)
 
 
 class _HarvestRender(torch.Tensor):

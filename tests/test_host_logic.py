@@ -360,3 +360,12 @@ def test_harvest_render_shortcut_and_its_fallbacks():
     # two statements on one render accumulate like any two uses
     r = render()
     assert torch.allclose(grad_of((r * f).sum() + (r * (2 * f)).sum()), 3 * f)
+    # the placeholder inside a LIST argument is the literal product too (never the detached zeros it physically is)
+    st = torch.stack([render() * f, render() * (2 * f)])
+    assert st.requires_grad and torch.allclose(grad_of(st.sum()), 3 * f)
+    # feats written in place between the statement and its backward: an error, as for the literal product's saved operand
+    f2 = f.clone()
+    s = (render() * f2).sum()
+    f2.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        s.backward()
