@@ -831,6 +831,8 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
             return set_error(GWBP_EINVAL, "gwbp_blend_scatter: a full-resolution map with unit channel stride is required");
         if (!M->p || !F)
             return set_error(GWBP_EINVAL, "null feats / F");
+        if (M->fs_y < 0 || M->fs_x < 0)
+            return set_error(GWBP_EINVAL, "gwbp_blend_scatter: negative strides (%lld %lld)", (long long)M->fs_y, (long long)M->fs_x);
         fu.feats = M->p, fu.fs_y = M->fs_y, fu.fs_x = M->fs_x, fu.D = D, fu.scale_f = scale_f, fu.F = F;
         fu.vec4 = (D % 4 == 0 && M->fs_y % 4 == 0 && M->fs_x % 4 == 0 && (reinterpret_cast<uintptr_t>(M->p) & 15) == 0) ? 1 : 0;
         if (fused_enc) {

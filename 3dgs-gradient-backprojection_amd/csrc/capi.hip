@@ -137,7 +137,6 @@ int make_layout(const gwbp_caps *c, Layout *L)
     // + 128 entries of slack behind the pool: k_scatter_wide's L2 warm-up touches one dword per 128-B line of a visit's run and
     // may reach one line past its end; its scalar batch loads stay inside the record's padded lists
     L->wpool = take((size_t)L->pair_cap * sizeof(WPair) + 1024);
-                                                                  // without clamping to the visit's length
     L->total = o;
     return GWBP_OK;
 }
