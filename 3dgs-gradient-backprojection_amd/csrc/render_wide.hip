@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void k_render_rows(ViewDev V, int n_chunks, co
 // channel quads (lane l: channels 4 l .. 4 l + 3 of each of the chunk's Q blocks of 256; lanes past the end of a partial last
 // block re-read a valid address and store nothing).
 // Round 5: k_render_rows issues ~70 instructions per (record, row) visit -- 29 vector, 40 scalar -- of which ~6 are FMAs, and it
-// is bound by exactly that: a SIMD issues one vector and one scalar instruction per four cycles (SQ_ACTIVE_INST_VALU +
-// SQ_ACTIVE_INST_SCA = 2.5 G quad-cycles per launch against 7.9 G SIMD-cycles; C2, D = 512: 5.37 ms for 7.1 GB).  The visit's
+// is bound by exactly that: a SIMD issues one vector and one scalar instruction per four cycles, from different waves
+// (SQ_ACTIVE_INST_VALU 61 %, SQ_ACTIVE_INST_SCA 65 % of the SIMD time; C2, D = 512: 5.37 ms for 7.1 GB).  The visit's
 // bookkeeping (three readlanes, addresses, the walk over the 16 mask bits) does not depend on the channel count, so it is paid
 // once per 256 (Q = 1: 3.0 ms) or 512 channels (Q = 2) instead of once per 128, and a pair costs one v_readlane + 2 Q
 // v_pk_fma_f32.  Same order of additions per pixel as k_render_rows: bit-identical output.
