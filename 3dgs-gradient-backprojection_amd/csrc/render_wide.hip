@@ -2,7 +2,7 @@
 //   out[p, :] = sum_g w_g(p) * colors[g, :]          (render_colors of rasterization(); segment.py:209-220 renders the
 //   512-d feature field this way, and the drop-in operator's forward needs it for the reference's own loop).
 //
-// k_render_rows (D < 256 or D % 4 != 0): a wave owns ONE ROW of a tile (16 pixels) for one 128-channel chunk; lanes = channel pairs.
+// k_render_rows (D < 128 or D % 4 != 0): a wave owns ONE ROW of a tile (16 pixels) for one 128-channel chunk; lanes = channel pairs.
 // k_render_rows4 (everything else, further down): the same walk with four or eight channels per lane.  The 16 accumulators are
 // registers (float2 acc[16]), so there is no LDS image and no read-modify-write chain: a pair costs one v_readlane (w)
 // and one v_pk_fma_f32 -- the pixel is a compile-time index because the row's 16 mask bits are tested one by one with
@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void k_render_rows(ViewDev V, int n_chunks, co
 }
 
 
-// D >= 256, D % 4 == 0 (the 512-d field of segment.py:209-220): a wave owns one tile row for a chunk of 256 * Q channels, lanes =
+// D >= 128, D % 4 == 0 (the 512-d field of segment.py:209-220; D = 192: 1.56 ms instead of two 128-channel chunks = 2.44, D = 132:
+// 1.47 where k_render_rows takes 1.53 for 128): a wave owns one tile row for a chunk of 256 * Q channels, lanes =
 // channel quads (lane l: channels 4 l .. 4 l + 3 of each of the chunk's Q blocks of 256; lanes past the end of a partial last
 // block re-read a valid address and store nothing).
 // Round 5: k_render_rows issues ~70 instructions per (record, row) visit -- 29 vector, 40 scalar -- of which ~6 are FMAs, and it
@@ -303,7 +304,7 @@ int launch_render(const Layout &L, const Ws &W, const ViewDev &V, const float *c
     (void)L;
     const int n_tiles = V.tile_w * V.tile_h;
     const int n_tiles_pad = (n_tiles + 7) & ~7;
-    if (D >= 256 && D % 4 == 0 && ((reinterpret_cast<uintptr_t>(colors) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 &&
+    if (D >= 128 && D % 4 == 0 && ((reinterpret_cast<uintptr_t>(colors) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 &&
         !profile_knob("GWBP_RENDER_NARROW")) {
         // whole blocks of 512 channels: 512 per wave (C2, D = 512: 2.75 ms against 3.05 with 256 per wave; 166 registers, three
         // waves per SIMD); what is left (<= 511 channels) in blocks of 256, the last one possibly partial

@@ -201,7 +201,7 @@ def test_render_forward_parity(orc, dev):
     cfg, sc = scene_np("T1")
     d, h = to_dev(sc, dev), npy(sc)
     eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev)
-    for D in (3, 20, 256, 260, 512, 708):  # (D >= 256, D % 4 == 0: k_render_rows4 -- 512 channels per wave for whole blocks of 512,
+    for D in (3, 20, 128, 132, 256, 260, 512, 708):  # (D >= 128, D % 4 == 0: k_render_rows4 -- 512 channels per wave for whole blocks of 512,
         # 256 per wave for the rest, a partial last block)
         colors = torch.rand(cfg.n_gaussians, D, generator=torch.Generator().manual_seed(5))
         view, _, _ = _front(eng, d, cfg, 1, want=False)
