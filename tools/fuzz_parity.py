@@ -22,6 +22,7 @@ DIMS = [1, 3, 4, 7, 8, 12, 16, 17, 32, 40, 64, 65, 100, 128, 130, 256, 384, 512,
 bad = 0
 n_fused = 0
 n_enc = 0
+n_render = 0
 t0 = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
@@ -113,10 +114,26 @@ for case in range(n_cases):
     eF = rel_row_err(F.cpu().numpy(), Fr) if info["n_pairs"] else 0.0
     ed = rel_row_err(d.cpu().numpy()[:, None], dr[:, None]) if info["n_pairs"] else 0.0
     ok = ok and eF <= 1e-4 and ed <= 1e-4 and (tight or st["n_isect"] == info["n_isect"])
+    # the forward render of a random colour table over the same view (gwbp_render: k_render_rows for D_r < 128 or D_r % 4 != 0,
+    # k_render_rows4 with 256 / 512 channels per wave otherwise) against the oracle's
+    if ok and rng.random() < 0.5:
+        Dr = int(rng.choice([5, 20, 64, 127, 128, 132, 200, 256, 260, 384, 512, 516, 708, 1024]))
+        cols = torch.randn(n, Dr, generator=g)
+        if fused or enc is not None:  # those paths left no weight store behind
+            eng.blend_weights(view)
+        out = eng.render(view, cols.to(dev)).cpu().numpy()
+        rp = orc.project(means.numpy(), quats.numpy(), scales.numpy(), vm.numpy(), K.numpy(), W, H)
+        rb = orc.bin_sort(rp, W, H)
+        ref, _ = orc.render(rp, rb, opac.numpy(), cols.numpy(), W, H)
+        er = float(np.abs(out - ref).max()) / max(1.0, float(np.abs(ref).max()))
+        n_render += 1
+        if eng.stats()["overflow"] or er > 2e-5:
+            ok = False
+            print(f"render D_r={Dr}: max error {er:.2e} overflow {eng.stats()['overflow']}", flush=True)
     if not ok:
         bad += 1
         print(f"FAIL case {seed0 + case}: N={n} {W}x{H} D={D} s0={s0:.4f} {layout} up={up} wide={wide} tight={tight} fused={fused} enc={None if enc is None else tuple(enc.shape)} "
               f"pairs {st['n_pairs']}/{info['n_pairs']} eF={eF:.2e} ed={ed:.2e} overflow={st['overflow']}", flush=True)
-print(f"{n_cases} cases ({n_fused} through the fused blend+scatter kernel, {n_enc} through the encoder-fused one), {bad} failures, "
+print(f"{n_cases} cases ({n_fused} through the fused blend+scatter kernel, {n_enc} through the encoder-fused one, {n_render} also rendered forward), {bad} failures, "
       f"{time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
