@@ -168,9 +168,14 @@ __global__ __launch_bounds__(256) void k_render_rows(ViewDev V, int n_chunks, co
 // pixel and left behind its last entry -- two or three taken branches per visit instead of one per set bit and one back -- is 4 %
 // SLOWER: it needs five scalar instructions per pair, and scalar issue counts like vector issue; testing the mask nibble by
 // nibble first changes nothing; more visits in flight per wave lose: 2 / 4 / 6 / 8 slots -> 3.20 / 3.07 / 3.38 / 3.47 ms at
-// Q = 1, the registers cost occupancy.)
+// Q = 1, the registers cost occupancy; ONE stream of visits over all the tile's records -- the next 64 headers prefetched, the
+// slots never drained between header blocks -- 2.88 against 2.75: the extra test in every refill costs more than the two round
+// trips per block it hides.)
 #ifndef GWBP_RENDER_SLOTS
-#define GWBP_RENDER_SLOTS 4
+#define GWBP_RENDER_SLOTS 4 // visits in flight per wave at 256 channels per wave (95 VGPRs: five waves per SIMD) ...
+#endif
+#ifndef GWBP_RENDER_SLOTS2
+#define GWBP_RENDER_SLOTS2 3 // ... and at 512 (166 VGPRs: three waves per SIMD)
 #endif
 
 template <int Q, int SLOTS>
@@ -314,7 +319,7 @@ int launch_render(const Layout &L, const Ws &W, const ViewDev &V, const float *c
         const int n8 = D / 512;
 #endif
         if (n8 > 0)
-            hipLaunchKernelGGL((k_render_rows4<2, 3>), dim3((unsigned)n_tiles_pad * 4u * (unsigned)n8), dim3(256), 0, s, V, n8,
+            hipLaunchKernelGGL((k_render_rows4<2, GWBP_RENDER_SLOTS2>), dim3((unsigned)n_tiles_pad * 4u * (unsigned)n8), dim3(256), 0, s, V, n8,
                                W.tile_offsets, W.hdr_count, W.headers, W.wpool, colors, D, out, 0);
         const int rest = D - 512 * n8, n4 = (rest + 255) / 256;
         if (n4 > 0)
