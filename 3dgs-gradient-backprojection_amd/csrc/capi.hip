@@ -439,8 +439,8 @@ int gwbp_render_pixels(const gwbp_caps *caps, void *workspace, size_t workspace_
         return rc;
     if ((rc = make_view(view_host, caps, &V)))
         return rc;
-    if (!colors || !out || D < 1 || D > 4)
-        return set_error(GWBP_EINVAL, "render_pixels needs colors, out and 1 <= D <= 4 (got D=%d)", D);
+    if (!colors || !out || D < 1 || D > 32)
+        return set_error(GWBP_EINVAL, "render_pixels needs colors, out and 1 <= D <= 32 (got D=%d)", D);
     return launch_render_px(W, V, colors, D, out, alphas, static_cast<hipStream_t>(stream));
 }
 

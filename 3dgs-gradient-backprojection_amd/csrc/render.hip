@@ -1,4 +1,5 @@
-// render.hip -- forward colour render for few channels (D <= 4: RGB, RGB+D, depth) and SH colour evaluation.
+// render.hip -- forward colour render for few channels (D <= 32: RGB, RGB+D, depth, the 16-d compressed field) and SH colour
+// evaluation.
 //
 // "Next" row N3 of SURVEY.md section 8(f): the step BEFORE the hot path in the reference (backproject.py:89-100 renders
 // the view with sh_degree=3 and feeds it to the 2-D feature network) and utils.test_proper_pruning (utils.py:316-340).
@@ -9,14 +10,20 @@
 
 namespace gwbp {
 
+// CH = channels held per pixel (4, 16 or 32; D <= CH).  Round 5: CH > 4 -- segment_compressed.py:154-165 renders the 16-d
+// compressed field this way for every frame; through the weight store (k_blend, then k_render_rows with 8 of 64 lanes at work)
+// that cost 0.75 + 1.13 ms at C2 -- and two wave-uniform early-outs taken from k_blend, neither of which changes a bit of the
+// result: a candidate whose alpha >= 1/255 ellipse holds no live pixel of the wave's 4 x 16 quarter skips exp and T (sigma
+// above ln(255 o) + margin cannot reach 1/255), one that contributes to no pixel skips its colour reads and FMAs.
+template <int CH>
 __global__ __launch_bounds__(256) void k_render_px(ViewDev V, const u32 *__restrict__ tile_offsets,
                                                    const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
                                                    const float *__restrict__ colors, int D,
                                                    float *__restrict__ out, float *__restrict__ alphas)
 {
-    __shared__ float4 s_a[256]; // mx, my, opac, -
+    __shared__ float4 s_a[256]; // mx, my, opac, ln(255 opac) + margin
     __shared__ float4 s_b[256]; // ca, cb, cc, -
-    __shared__ float4 s_c[256]; // colour (up to 4 channels)
+    __shared__ float4 s_c[256][CH / 4]; // colour
     const int tile = blockIdx.x;
     const int tx = tile % V.tile_w, ty = tile / V.tile_w;
     const int lane = threadIdx.x & 63;
@@ -27,7 +34,10 @@ __global__ __launch_bounds__(256) void k_render_px(ViewDev V, const u32 *__restr
     const u32 beg = tile_offsets[tile], end = tile_offsets[tile + 1];
     float T = 1.0f;
     bool done = !inside;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        acc[c] = 0.f;
     for (u32 batch = beg; batch < end; batch += 256) {
         if (__syncthreads_count(done) == 256)
             break;
@@ -35,49 +45,58 @@ __global__ __launch_bounds__(256) void k_render_px(ViewDev V, const u32 *__restr
         if (threadIdx.x < bn) {
             const u32 gid = vals[batch + threadIdx.x];
             const float4 *gp = reinterpret_cast<const float4 *>(g2d + gid);
-            s_a[threadIdx.x] = gp[0];
+            float4 a = gp[0];
+            // alpha = o exp(-sigma) >= 1/255  <=>  sigma <= ln(255 o); 1e-3 absorbs the error of __logf and exp_neg (k_blend's
+            // s_thr); o <= 1/255 gives a negative bound that no sigma >= 0 meets
+            a.w = __logf(255.0f * a.z) + 1e-3f;
+            s_a[threadIdx.x] = a;
             s_b[threadIdx.x] = gp[1];
-            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
             const float *cp = colors + (size_t)gid * D;
-            c.x = cp[0];
-            if (D > 1)
-                c.y = cp[1];
-            if (D > 2)
-                c.z = cp[2];
-            if (D > 3)
-                c.w = cp[3];
-            s_c[threadIdx.x] = c;
+            float cv[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                cv[c] = c < D ? cp[c] : 0.f;
+#pragma unroll
+            for (int c4 = 0; c4 < CH / 4; ++c4)
+                s_c[threadIdx.x][c4] = make_float4(cv[4 * c4], cv[4 * c4 + 1], cv[4 * c4 + 2], cv[4 * c4 + 3]);
         }
         __syncthreads();
         for (u32 j = 0; j < bn; ++j) {
             if (__ballot(!done) == 0ull)
                 break;
-            const float4 a = s_a[j], b = s_b[j], c = s_c[j];
+            const float4 a = s_a[j], b = s_b[j];
             const float dx = a.x - px, dy = a.y - py;
             const float sigma = __builtin_fmaf(b.y * dx, dy, 0.5f * __builtin_fmaf(b.x * dx, dx, (b.z * dy) * dy));
+            if (__ballot(!done && sigma <= a.w) == 0ull)
+                continue; // no live pixel of this quarter inside the alpha >= 1/255 ellipse
             const float alpha = __builtin_fminf(kAlphaMax, a.z * exp_neg(-__builtin_fmaxf(sigma, 0.f)));
             const bool ok = !done && (sigma >= 0.f) && (alpha >= kAlphaMin);
             const float next_T = T * (1.0f - alpha);
             const bool term = ok && (next_T <= kTMin);
             const bool valid = ok && !term;
             const float w = valid ? alpha * T : 0.f;
-            acc.x = __builtin_fmaf(w, c.x, acc.x);
-            acc.y = __builtin_fmaf(w, c.y, acc.y);
-            acc.z = __builtin_fmaf(w, c.z, acc.z);
-            acc.w = __builtin_fmaf(w, c.w, acc.w);
             T = valid ? next_T : T;
             done = done || term;
+            if (__ballot(valid) == 0ull)
+                continue; // nobody takes colour from this Gaussian
+#pragma unroll
+            for (int c4 = 0; c4 < CH / 4; ++c4) {
+                const float4 c = s_c[j][c4];
+                // (valid ? : instead of a plain w = 0 product: a non-finite colour must reach only the pixels the Gaussian has a
+                // weight at, as in k_render_rows, which never multiplies at all where the record has no entry)
+                acc[4 * c4] = valid ? __builtin_fmaf(w, c.x, acc[4 * c4]) : acc[4 * c4];
+                acc[4 * c4 + 1] = valid ? __builtin_fmaf(w, c.y, acc[4 * c4 + 1]) : acc[4 * c4 + 1];
+                acc[4 * c4 + 2] = valid ? __builtin_fmaf(w, c.z, acc[4 * c4 + 2]) : acc[4 * c4 + 2];
+                acc[4 * c4 + 3] = valid ? __builtin_fmaf(w, c.w, acc[4 * c4 + 3]) : acc[4 * c4 + 3];
+            }
         }
     }
     if (inside) {
         float *o = out + ((size_t)iy * V.W + ix) * D;
-        o[0] = acc.x;
-        if (D > 1)
-            o[1] = acc.y;
-        if (D > 2)
-            o[2] = acc.z;
-        if (D > 3)
-            o[3] = acc.w;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (c < D)
+                o[c] = acc[c];
         if (alphas)
             alphas[(size_t)iy * V.W + ix] = 1.0f - T;
     }
@@ -131,8 +150,15 @@ int launch_render_px(const Ws &W, const ViewDev &V, const float *colors, int D, 
 {
     const int n_tiles = V.tile_w * V.tile_h;
     const int fin = sort_passes(n_tiles) & 1;
-    hipLaunchKernelGGL(k_render_px, dim3(n_tiles), dim3(256), 0, s, V, W.tile_offsets, W.vals[fin], W.g2d, colors, D,
-                       out, alphas);
+#define GWBP_PX(C)                                                                                                    \
+    hipLaunchKernelGGL(k_render_px<C>, dim3(n_tiles), dim3(256), 0, s, V, W.tile_offsets, W.vals[fin], W.g2d, colors, D, out, alphas)
+    if (D <= 4)
+        GWBP_PX(4);
+    else if (D <= 16)
+        GWBP_PX(16);
+    else
+        GWBP_PX(32);
+#undef GWBP_PX
     return check_hip(hipGetLastError(), "render_px launch");
 }
 

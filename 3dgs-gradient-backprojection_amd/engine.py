@@ -396,7 +396,7 @@ class Engine:
         return out
 
     def render_pixels(self, view, colors, want_alphas=True):
-        """Pixel-parallel forward render for 1..4 channels; needs project + bin_sort of `view` (not the weight store)."""
+        """Pixel-parallel forward render for 1..32 channels; needs project + bin_sort of `view` (not the weight store)."""
         colors = _req(colors, "colors")
         D = colors.shape[1]
         out = torch.empty(view.height, view.width, D, device=self.device)

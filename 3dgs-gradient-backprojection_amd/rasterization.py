@@ -33,6 +33,10 @@ _ZERO_RENDERS: Dict[Tuple, Tuple] = {}
 
 # rows of a table that are re-checked on EVERY call (see _is_zero_table)
 _SAMPLE_ROWS = 257
+# colour tables of at most this many channels are rendered by the pixel-parallel kernel (gwbp_render_pixels: no weight store;
+# C2: 0.59 ms for RGB, 0.91 ms for 16 channels, where blend + weight-store render take 0.75 + 1.13; the kernel goes up to 32
+# channels, but at 1.88 ms it no longer beats that route there)
+PIXEL_RENDER_MAX_DIM = 16
 
 
 def invalidate_zero_table_cache() -> None:
@@ -171,7 +175,7 @@ class _Rasterize(torch.autograd.Function):
         eng = get_engine(dev, means.shape[0], width, height)
         view = eng.view(viewmat, K, width, height, **kw)
         D = colors.shape[1]
-        need_store = colors.requires_grad or D > 4  # the weight store is only needed for backward / the wide render
+        need_store = colors.requires_grad or D > PIXEL_RENDER_MAX_DIM  # the weight store is only needed for backward / the wide render
         # a backward with D % 256 == 0 channels goes through the 256-channel scatter kernel, which needs the blend's
         # half-tile lists: the flag must be in place before this view's blend
         eng.set_narrow_scatter(not (colors.requires_grad and D % 256 == 0))
@@ -179,11 +183,12 @@ class _Rasterize(torch.autograd.Function):
         # back-propagated through (backproject.py:67-72,115-129,133-147) -- the render of zeros is zeros, for any D
         if harvest is None:
             harvest = colors.requires_grad and _is_zero_table(colors)
-        proj, bins, alphas, st = _run_front(eng, view, means, quats, scales, opacities, D > 4 or harvest,
+        proj, bins, alphas, st = _run_front(eng, view, means, quats, scales, opacities, D > PIXEL_RENDER_MAX_DIM or harvest,
                                             holder is not None, want_store=need_store)
         if harvest:
             out = _zero_render(dev, view.height, view.width, D)  # (alphas: the blend's, kept with the front-stage result)
-        elif D <= 4:  # RGB / RGB+D / depth: pixel-parallel rasteriser straight from the sorted tile lists
+        elif D <= PIXEL_RENDER_MAX_DIM:  # RGB / RGB+D / depth / the 16-d compressed field (segment_compressed.py:154-165):
+            # pixel-parallel rasteriser straight from the sorted tile lists
             out, alphas = eng.render_pixels(view, colors.detach())
         else:
             out = eng.render(view, colors.detach())

@@ -198,9 +198,10 @@ int gwbp_scatter_bilinear(const gwbp_caps *caps, void *workspace, size_t workspa
 int gwbp_render(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                 const float *colors, int32_t D, float *out, void *stream);
 
-/* Forward render for 1..4 channels (RGB, RGB+D, depth) straight from the sorted tile lists (needs gwbp_project +
- * gwbp_bin_sort of the same view, not the weight store): the render the reference feeds to its 2-D feature network
- * (backproject.py:89-100) and compares in utils.test_proper_pruning (utils.py:316-340).  alphas[H*W] optional. */
+/* Forward render for 1..32 channels (RGB, RGB+D, depth; round 5: the 16-d compressed field) straight from the sorted tile
+ * lists (needs gwbp_project + gwbp_bin_sort of the same view, not the weight store): the render the reference feeds to its
+ * 2-D feature network (backproject.py:89-100), compares in utils.test_proper_pruning (utils.py:316-340) and scores per frame
+ * in segment_compressed.py:154-165.  alphas[H*W] optional. */
 int gwbp_render_pixels(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                        const float *colors, int32_t D, float *out, float *alphas, void *stream);
 

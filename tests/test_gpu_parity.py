@@ -434,6 +434,50 @@ def test_sh_rgb_render_through_shim(orc, dev):
     assert np.abs(outd[0].cpu().numpy() - refd).max() < 2e-5
 
 
+@pytest.mark.parametrize("cfg_name", ["T1", "T0"])
+def test_pixel_render_up_to_32_channels(orc, dev, cfg_name):
+    """gwbp_render_pixels for 5..32 channels (round 5: segment_compressed.py:154-165 renders the 16-d compressed field per
+    frame; no weight store needed): colours vs the oracle's render, the alpha map bit for bit, a non-finite colour only where
+    its Gaussian has weight, the wide kernel's output for the same table, and the drop-in's route (D <= 32 -> this kernel)."""
+    from gsbp_amd import rasterization
+    cfg, sc = scene_np(cfg_name)
+    d, h = to_dev(sc, dev), npy(sc)
+    N, W, H = cfg.n_gaussians, cfg.width, cfg.height
+    eng = gsbp_amd.Engine(N, W, H, device=dev)
+    view, _, _ = _front(eng, d, cfg, 1, want=False)
+    ref_p = orc.project(h["means"], h["quats"], h["scales"], h["vms"][1], h["K"], W, H)
+    ref_b = orc.bin_sort(ref_p, W, H)
+    for D in (1, 4, 5, 16, 20, 32):
+        cols = torch.randn(N, D, generator=torch.Generator().manual_seed(D))
+        out, alpha = eng.render_pixels(view, cols.to(dev))
+        ref, ralpha = orc.render(ref_p, ref_b, h["opac"], cols.numpy(), W, H)
+        assert out.shape == (H, W, D)
+        assert np.abs(out.cpu().numpy() - ref).max() <= 1e-5
+        assert np.array_equal(alpha.cpu().numpy().view(np.uint32), ralpha.view(np.uint32))
+    # the weight-store render of the same table: same order of additions, same fused multiply-adds
+    cols = torch.randn(N, 16, generator=torch.Generator().manual_seed(99))
+    out_px, _ = eng.render_pixels(view, cols.to(dev))
+    eng.blend_weights(view)
+    assert torch.equal(out_px, eng.render(view, cols.to(dev)))
+    # a NaN colour reaches exactly the pixels its Gaussian has a weight at
+    gid, pix, w, _ = orc.blend_pairs(ref_p, ref_b, h["opac"], W, H)
+    g_bad = int(np.bincount(gid, minlength=N).argmax())
+    cols_bad = cols.clone()
+    cols_bad[g_bad, 3] = float("nan")
+    out_bad, _ = eng.render_pixels(view, cols_bad.to(dev))
+    hit = np.zeros(H * W, bool)
+    hit[pix[gid == g_bad]] = True
+    nan_map = torch.isnan(out_bad[..., 3]).cpu().numpy().reshape(-1)
+    assert hit.any() and np.array_equal(nan_map, hit)
+    assert not torch.isnan(out_bad[..., :3]).any() and not torch.isnan(out_bad[..., 4:]).any()
+    with pytest.raises(gsbp_amd.GwbpError):
+        eng.render_pixels(view, torch.zeros(N, 33, device=dev))
+    with torch.no_grad():
+        o, a, _ = rasterization(d["means"], d["quats"], d["scales"], d["opac"], cols.to(dev), d["vms"][1][None], d["K"][None],
+                                width=W, height=H, want_meta=False)
+    assert torch.equal(o[0], out_px) and o.shape == (1, H, W, 16)
+
+
 def test_prune_mask_equals_reference_rule(orc, dev):
     """utils.prune_by_gradients (utils.py:222-271): keep Gaussians with accumulated |colour grad| > 0 == d > 0."""
     cfg, sc = scene_np("T1")

@@ -1,4 +1,4 @@
-"""C2-size timing of the RGB forward render (`gwbp_render_pixels`, D <= 4: backproject.py:89-100 renders the view it feeds to the 2-D network
+"""C2-size timing of the RGB forward render (`gwbp_render_pixels`, D <= 32: backproject.py:89-100 renders the view it feeds to the 2-D network
 this way) and of the SH colour evaluation in front of it; project + sort once, then each kernel REPS times.  GPU only.
 usage: python3 tools/time_render_px.py [D] [reps] [config] [library]"""
 import sys
