@@ -135,7 +135,8 @@ int make_layout(const gwbp_caps *c, Layout *L)
     L->headers = take((size_t)L->isect_cap * sizeof(Header));
     L->carry = take((size_t)kCarryWgs * kCarryRows * 256 * sizeof(float));
     // + 128 entries of slack behind the pool: k_scatter_wide's L2 warm-up touches one dword per 128-B line of a visit's run and
-    // may reach one line past its end; its scalar batch loads stay inside the record's padded lists
+    // may reach one line past its end (its scalar batch loads stay inside the record's padded lists), and k_render_rows4 reads
+    // 16 entries from a visit's first one whatever the visit's length (15 entries = 120 B past the last record at most)
     L->wpool = take((size_t)L->pair_cap * sizeof(WPair) + 1024);
     L->total = o;
     return GWBP_OK;
