@@ -23,6 +23,7 @@ bad = 0
 n_fused = 0
 n_enc = 0
 n_render = 0
+n_px = 0
 t0 = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
@@ -130,10 +131,24 @@ for case in range(n_cases):
         if eng.stats()["overflow"] or er > 2e-5:
             ok = False
             print(f"render D_r={Dr}: max error {er:.2e} overflow {eng.stats()['overflow']}", flush=True)
+    # the pixel-parallel render (gwbp_render_pixels, 1..32 channels, no weight store): colours and the alpha map (bit for bit)
+    if ok and rng.random() < 0.4:
+        Dp = int(rng.choice([1, 3, 4, 5, 9, 16, 17, 32]))
+        cols = torch.randn(n, Dp, generator=g)
+        out, alpha = eng.render_pixels(view, cols.to(dev))
+        rp = orc.project(means.numpy(), quats.numpy(), scales.numpy(), vm.numpy(), K.numpy(), W, H)
+        rb = orc.bin_sort(rp, W, H)
+        ref, ralpha = orc.render(rp, rb, opac.numpy(), cols.numpy(), W, H)
+        er = float(np.abs(out.cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max()))
+        same_alpha = np.array_equal(alpha.cpu().numpy().view(np.uint32), ralpha.view(np.uint32))
+        n_px += 1
+        if er > 2e-5 or not same_alpha:
+            ok = False
+            print(f"render_pixels D={Dp}: max error {er:.2e} alpha identical {same_alpha}", flush=True)
     if not ok:
         bad += 1
         print(f"FAIL case {seed0 + case}: N={n} {W}x{H} D={D} s0={s0:.4f} {layout} up={up} wide={wide} tight={tight} fused={fused} enc={None if enc is None else tuple(enc.shape)} "
               f"pairs {st['n_pairs']}/{info['n_pairs']} eF={eF:.2e} ed={ed:.2e} overflow={st['overflow']}", flush=True)
-print(f"{n_cases} cases ({n_fused} through the fused blend+scatter kernel, {n_enc} through the encoder-fused one, {n_render} also rendered forward), {bad} failures, "
+print(f"{n_cases} cases ({n_fused} through the fused blend+scatter kernel, {n_enc} through the encoder-fused one, {n_render} also rendered forward, {n_px} through the pixel-parallel render), {bad} failures, "
       f"{time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
