@@ -22,7 +22,11 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 # back to back: 5.06 instead of 4.27 ms/view at C2 when this was found).
 HW_QUEUES_WANTED = 8
 _QUEUES_LATE = "GPU_MAX_HW_QUEUES" not in os.environ and torch.cuda.is_initialized()
-os.environ.setdefault("GPU_MAX_HW_QUEUES", str(HW_QUEUES_WANTED))
+# SIDE EFFECT OF IMPORTING THIS PACKAGE: os.environ["GPU_MAX_HW_QUEUES"] = "8" unless the variable is already set (child
+# processes inherit it, which is what a launcher of per-GPU ranks wants).  When the runtime is already up the variable would
+# change nothing in this process, so it is left alone: the environment then still says what the runtime really read.
+if not _QUEUES_LATE:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(HW_QUEUES_WANTED))
 
 
 def hw_queues_late() -> bool:
@@ -83,17 +87,39 @@ class GwbpError(RuntimeError):
     pass
 
 
+PROFILE_LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "tools", "lib", "libgwbp_profile.so"))
+
+
+def _sources():
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".map")) or f == "Makefile"]
+    srcs.append(os.path.join(_HERE, "..", "include", "gwbp.h"))
+    srcs.append(os.path.join(_HERE, "..", "tools", "check_asm_hazards.py"))  # the build-time gate of scatter_wide
+    return [s for s in srcs if os.path.exists(s)]
+
+
+def _stale(target: str) -> bool:
+    return not os.path.exists(target) or any(os.path.getmtime(s) > os.path.getmtime(target) for s in _sources())
+
+
 def build(force: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into the in-tree libgwbp.so (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
-    srcs.append(os.path.join(_HERE, "..", "include", "gwbp.h"))
-    stale = force or not os.path.exists(LIB_PATH) or any(
-        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s))
-    if stale:
+    if force or _stale(LIB_PATH):
         if not os.path.exists("/opt/rocm/bin/hipcc"):
             raise GwbpError("libgwbp.so is stale/missing and hipcc is not available to rebuild it")
         subprocess.check_call(["make", "-C", CSRC, "-s", "-j8"])
     return LIB_PATH
+
+
+def build_profile(force: bool = False) -> str:
+    """`make PROFILE=1`: tools/lib/libgwbp_profile.so from the SAME sources as the product library (ablation knobs + in-kernel
+    stamps: another register allocation of every kernel).  It is the subject of the differential test of the 256-channel scatter
+    kernel against the 128-channel one (tests/test_gpu_parity.py); __graft_entry__.build() keeps it current so that the test
+    never runs on a stale binary.  Never loaded by the product path (use_library(..., allow_profile=True) only)."""
+    if force or _stale(PROFILE_LIB_PATH):
+        if not os.path.exists("/opt/rocm/bin/hipcc"):
+            raise GwbpError("libgwbp_profile.so is stale/missing and hipcc is not available to rebuild it")
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j8", "PROFILE=1"])
+    return PROFILE_LIB_PATH
 
 
 _P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t

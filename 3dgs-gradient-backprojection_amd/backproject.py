@@ -111,6 +111,48 @@ def finalize_reference(F: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
     return x
 
 
+# verdict of wide_kernel_selfcheck per (library path, device index): the check runs once per process and device
+_WIDE_OK: Dict[tuple, bool] = {}
+WIDE_SELFCHECK_TOL = 1e-6
+
+
+def wide_kernel_selfcheck(device) -> bool:
+    """Does the 256-channel scatter kernel of THIS build agree with the 128-channel one on THIS device?
+
+    k_scatter_wide keeps asm-issued loads and two fixed SGPR tuples live across inline-asm statements; the build is gated by an
+    assembly scan (tools/check_asm_hazards.py, run by the Makefile for every variant), and this is the run-time half of the same
+    safety net: one small seeded view (T1: 4000 Gaussians, 200x136, D = 256 -- records in one half, in both halves, padded
+    lists, carry rows) is blended once and scattered through both kernels; they must agree to 1e-6 of the largest row (the
+    kernels differ only in summation order: 1.4e-7 measured over every build variant of round 5).  On disagreement
+    ViewPipeline.choose_scatter_kernel warns and stays on the 128-channel kernel -- 5 % slower at BASELINE size, never wrong.
+    A few milliseconds, once per process and device, before the first D % 256 == 0 job."""
+    from . import _lib, synthetic as syn
+    dev = torch.device(device)
+    key = (_lib._lib_path, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key in _WIDE_OK:
+        return _WIDE_OK[key]
+    cfg = syn.CONFIGS["T1"]
+    means, quats, scales, opac = [t.to(dev) for t in syn.activate(syn.make_scene(cfg))]
+    K, vm = syn.intrinsics(cfg), syn.make_cameras(cfg)[0]
+    feats = syn.make_feature_map(cfg, 0, device=dev, dim=256)
+    res = []
+    for wide in (True, False):
+        eng = Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, tight_binning=True)
+        eng.set_narrow_scatter(not wide)
+        view = eng.view(vm, K, cfg.width, cfg.height)
+        eng.project(view, means, quats, scales, opac)
+        eng.bin_sort(view)
+        eng.blend_weights(view)
+        F = torch.zeros(cfg.n_gaussians, 256, device=dev)
+        eng.scatter(view, feats, F, None)
+        res.append(F)
+    scale = res[1].norm(dim=1).max().clamp_min(1e-30)
+    diff = (res[0] - res[1]).norm(dim=1).max() / scale
+    ok = bool(torch.isfinite(res[0]).all()) and bool(res[1].abs().sum() > 0) and float(diff) <= WIDE_SELFCHECK_TOL
+    _WIDE_OK[key] = ok
+    return ok
+
+
 class ViewPipeline:
     """Software pipeline over views on the caller's stream + side streams, one workspace per view in flight (two by default).
 
@@ -211,6 +253,12 @@ class ViewPipeline:
         wide = self.allow_wide and self.scatter_dim is not None and self.scatter_dim % 256 == 0
         if wide and n_pairs is not None and n_headers:
             wide = n_pairs / n_headers >= self.WIDE_MIN_PAIRS_PER_RECORD
+        if wide and self.dev.type == "cuda" and not wide_kernel_selfcheck(self.dev):
+            import warnings
+            warnings.warn("the 256-channel scatter kernel of this build disagrees with the 128-channel one on the self-check "
+                          "view (wide_kernel_selfcheck): using the 128-channel kernel.  Rebuild libgwbp.so "
+                          "(python __graft_entry__.py) and report the toolchain version.", RuntimeWarning)
+            wide = False
         self.wide = wide
         for e in self.eng:
             e.set_narrow_scatter(not wide)
@@ -496,6 +544,19 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     stats: Dict[str, int] = {}
     if view_fn is None:
         eng = engine or Engine(n, width, height, device=dev, tight_binning=True)  # same F and d, shorter tile lists
+        if pipeline and len(my_views) > 1:
+            from . import _lib
+            if _lib.hw_queues_late():
+                # Somebody touched the GPU before this package was imported (a notebook, another library): the request for
+                # hardware queues came too late and the pipeline's streams would share queues.  That costs speed, not results,
+                # so the DRIVER degrades by itself: one stream, same F and d.  Constructing a ViewPipeline
+                # explicitly still raises -- whoever asks for the overlapped schedule by name should hear that it cannot run.
+                import warnings
+                warnings.warn("gsbp_amd was imported after the HIP runtime had started: GPU_MAX_HW_QUEUES=%d could not be "
+                              "requested, create_feature_field runs its views on ONE stream (pipeline=False; ~20 %% slower at "
+                              "BASELINE size).  Import gsbp_amd, or set the variable, before the first CUDA/HIP call."
+                              % _lib.HW_QUEUES_WANTED, RuntimeWarning, stacklevel=2)
+                pipeline = False
         for attempt in range(6):  # a capacity overflow invalidates the accumulators: grow the workspace, start over
             if pipeline and len(my_views) > 1:
                 first_map = feature_fn(my_views[0]) if encoder is not None else None

@@ -842,6 +842,11 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
                                  M->enc_k);
             if (M->fs_y % 4 != 0 || M->fs_x % 4 != 0 || (reinterpret_cast<uintptr_t>(M->p) & 15) != 0 || M->fs_x < M->enc_k)
                 return set_error(GWBP_EINVAL, "gwbp_blend_scatter_encoded: pixels must be 16-B aligned runs of K contiguous channels");
+            // the prologue addresses a pixel as wave-uniform row base + ONE 32-bit per-lane byte offset (column * fs_x + k-block)
+            if (((int64_t)(V.W - 1) * M->fs_x + M->enc_k) * (int64_t)sizeof(float) >= (int64_t)1 << 32)
+                return set_error(GWBP_EINVAL, "gwbp_blend_scatter_encoded: a row spans %lld bytes, the kernel's per-lane offsets are "
+                                 "32-bit (width %d, pixel stride %lld floats): encode with gwbp_encode_map instead",
+                                 (long long)(((int64_t)(V.W - 1) * M->fs_x + M->enc_k) * 4), V.W, (long long)M->fs_x);
             fu.enc = M->enc, fu.enc_k = M->enc_k;
         }
     }

@@ -236,9 +236,11 @@ class Engine:
             return False
         sy, sx, sc = feats.stride()
         K, n = encoder.shape
+        # (a row must span less than 4 GB: the kernel's per-lane column offsets are 32-bit -- a channel slice of a much wider
+        # tensor falls back to encode_map, like any other layout the kernel does not take)
         return (feats.is_cuda and feats.dtype == torch.float32 and encoder.dtype == torch.float32 and 1 <= n <= 16
                 and K % 16 == 0 and 16 <= K <= 512 and sc == 1 and sy % 4 == 0 and sx % 4 == 0 and sy >= 0 and sx >= K
-                and feats.data_ptr() % 16 == 0)
+                and feats.data_ptr() % 16 == 0 and ((feats.shape[1] - 1) * sx + K) * 4 < (1 << 32))
 
     def blend_scatter_encoded(self, view, feats, encoder, F, d, scale_f=1.0, scale_d=1.0, want_alphas=False):
         """blend_scatter(view, feats @ encoder, ...) of the compressed variant (backproject_compressed.py:127-165) in ONE

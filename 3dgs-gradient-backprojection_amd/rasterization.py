@@ -61,13 +61,14 @@ def _is_zero_table(colors: torch.Tensor) -> bool:
     `invalidate_zero_table_cache()` is for."""
     key = id(colors)
     hit = _ZERO_TABLES.get(key)
-    if hit is not None and hit[0]() is colors and hit[1] == colors._version:
+    # (the storage address is part of the key: `t.data = other` keeps object and version but swaps the memory)
+    if hit is not None and hit[0]() is colors and hit[1] == colors._version and hit[3] == colors.data_ptr():
         if not hit[2] or _sample_is_zero(colors):
             return hit[2]
     z = not bool(colors.detach().any())
     if len(_ZERO_TABLES) > 16:
         _ZERO_TABLES.clear()
-    _ZERO_TABLES[key] = (weakref.ref(colors), colors._version, z)
+    _ZERO_TABLES[key] = (weakref.ref(colors), colors._version, z, colors.data_ptr())
     return z
 
 
@@ -261,7 +262,27 @@ def _scatter_grad(eng: Engine, view, g_out: torch.Tensor, acc: torch.Tensor) -> 
 # on the shortcut.  One visible difference: with non-finite values in feats (backproject.py:109 can produce NaN pixels) the
 # literal `target` is NaN and this one is 0; nothing in the reference reads it, and the gradient -- NaN at exactly those pixels --
 # is the same.
-_HARVEST_SHORTCUT = True
+# The two tensor subclasses below lean on private torch entry points; if a release drops one of them the shortcut switches
+# itself off at import (every statement is then computed literally -- slower, never wrong) and tests/test_host_logic.py fails
+# visibly on the missing name.
+PRIVATE_TORCH_APIS = ("torch._C.DisableTorchFunctionSubclass", "torch._C._disabled_torch_function_impl",
+                      "torch._C._will_engine_execute_node", "torch.utils._pytree.tree_map")
+
+
+def missing_private_apis():
+    import importlib
+    out = []
+    for name in PRIVATE_TORCH_APIS:
+        mod, _, attr = name.rpartition(".")
+        try:
+            if not hasattr(importlib.import_module(mod), attr):
+                out.append(name)
+        except ImportError:
+            out.append(name)
+    return out
+
+
+_HARVEST_SHORTCUT = not missing_private_apis()
 
 
 def set_harvest_shortcut(on: bool) -> None:
@@ -283,9 +304,12 @@ class _HarvestSum(torch.autograd.Function):
         return render.new_zeros(())
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         (feats,) = ctx.saved_tensors
+        if torch.is_grad_enabled() or (feats.is_cuda and torch.cuda.is_current_stream_capturing()):
+            # backward(create_graph=True) (grad mode is on inside backward only then) or a stream capture: no host read, and
+            # the literal product's gradient with its history -- d(sum(render * feats)) / d(render) = g * feats
+            return feats * (g * ctx.scale), None, None
         k = float(g) * ctx.scale  # (a host read of one scalar; the loop's other statements synchronise anyway)
         return (feats if k == 1.0 else feats * k), None, None
 
@@ -357,7 +381,7 @@ class _OneCameraBatch(torch.Tensor):
     [H,W,D] gradient into it -- 7 GB of traffic per view at C2 for an axis of length one.  `batch[0]` of this class hands back
     the [H,W,D] tensor the batch IS a view of (same storage, same autograd history, no extra node); every other index and
     every torch op behaves as on a plain tensor and returns plain tensors."""
-    __torch_function__ = torch._C._disabled_torch_function_impl
+    __torch_function__ = getattr(torch._C, "_disabled_torch_function_impl", torch.Tensor.__torch_function__)
 
     def __getitem__(self, idx):
         cam0 = getattr(self, "_camera0", None)

@@ -92,6 +92,14 @@ def main():
                          "results possibly INVALID) instead of the in-tree one; recorded in the line as config.library")
     args = ap.parse_args()
 
+    if args.gpus > 1 and not args.one_device:
+        # A mis-provisioned multi-GPU run must fail loudly HERE, not hang in init_process_group waiting for ranks whose devices do
+        # not exist.  (torch.cuda.device_count() does not start the HIP runtime on this image, so the launching parent stays clean.)
+        import torch as _t
+        have = _t.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s) (torch.cuda.device_count()); "
+                             "use --one-device with --dist-backend gloo to check the N > 1 bookkeeping on one GPU")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start N FRESH rank processes (one per GPU) under torch.distributed.run and
         # relay rank 0's JSON line.  Nothing in THIS process has touched the GPU (argparse only), and it never re-execs.

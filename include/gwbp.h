@@ -30,6 +30,15 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: the entry points below are its ONLY dynamic symbols (no C++ symbol of the
+ * implementation -- launchers taking hipStream_t, kernel host stubs -- crosses the boundary; tests/test_capi_cpu.py compares
+ * `nm -D --defined-only` with this header, both directions). */
+#if defined(__GNUC__) || defined(__clang__)
+#define GWBP_API __attribute__((visibility("default")))
+#else
+#define GWBP_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -97,36 +106,36 @@ typedef struct gwbp_stats {
 } gwbp_stats;
 
 /* Library / build identification ("gfx950;<git-less build tag>"). */
-const char *gwbp_version(void);
+GWBP_API const char *gwbp_version(void);
 /* Thread-local description of the last non-zero status returned on this thread. */
-const char *gwbp_last_error_string(void);
+GWBP_API const char *gwbp_last_error_string(void);
 
 /* Bytes of workspace needed for the given capacities (256-B aligned sub-buffers). */
-int gwbp_workspace_size(const gwbp_caps *caps, size_t *bytes_host);
+GWBP_API int gwbp_workspace_size(const gwbp_caps *caps, size_t *bytes_host);
 
 /* ---- stage entry points (replace the stages inside gsplat.rasterization) -------------------- */
 
 /* fully_fused_projection + tiles-per-Gaussian count.  Writes the projected table inside the workspace and,
  * if non-null, user-visible copies: radii[N] int32 (0 = culled), means2d[N,2], depths[N], conics[N,3]. */
-int gwbp_project(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_project(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                  const float *means, const float *quats, const float *scales, const float *opacities,
                  int32_t *radii, float *means2d, float *depths, float *conics, void *stream);
 
 /* isect_tiles + stable radix sort by (tile, depth) + isect_offset_encode.  Optional outputs:
  * isect_ids[isect_cap] int64 sorted keys, flatten_ids[isect_cap] int32, tile_offsets[tiles+1] int32. */
-int gwbp_bin_sort(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_bin_sort(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                   int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_offsets, void *stream);
 
 /* rasterize_to_pixels forward, weights only: per tile, front-to-back blend producing the sparse weight store
  * (w = alpha*T per contributing (Gaussian, pixel)) inside the workspace; alphas[H*W] (= 1 - T) optional. */
-int gwbp_blend_weights(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_blend_weights(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                        float *alphas, void *stream);
 
 /* gwbp_blend_weights that also adds the view's denominators, d[g] += scale_d * sum_p w_g(p), while it writes each
  * record (needs caps WITHOUT GWBP_FLAG_NARROW_SCATTER): what a caller that overlaps the front stage of view v+1 with
  * the scatter of view v uses on the front's stream (then d = NULL for gwbp_scatter) -- the whole denominator pass of
  * backproject.py:133-150 costs one 4-B atomic per (Gaussian, tile) record and no kernel of its own. */
-int gwbp_blend_weights_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_blend_weights_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                          float *alphas, float scale_d, float *d, void *stream);
 
 /* Blend AND scatter of one view in one kernel, for narrow maps (1 <= D <= 16; on images of at most 4096 tiles, where a wave
@@ -137,7 +146,7 @@ int gwbp_blend_weights_d(const gwbp_caps *caps, void *workspace, size_t workspac
  * left EMPTY: a later gwbp_scatter / gwbp_render of this view adds nothing and gwbp_stats.reserved reads 2), no scatter
  * kernel runs.  feats[y * fs_y + x * fs_x + c] full resolution, unit channel stride; d may be NULL; alphas optional.
  * The weights are those of gwbp_blend_weights bit for bit; F and d differ from gwbp_scatter's only by summation order. */
-int gwbp_blend_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_blend_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                        const float *feats, int64_t fs_y, int64_t fs_x, int32_t D, float scale_f, float scale_d,
                        float *F, float *d, float *alphas, void *stream);
 
@@ -147,7 +156,7 @@ int gwbp_blend_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_
  * scatters like gwbp_blend_scatter.  feats[y * fs_y + x * fs_x + k]: channel-contiguous 16-B aligned pixels, K % 16 == 0,
  * 16 <= K <= 512; encoder row-major [K, n_out].  Any image size.  Results equal gwbp_encode_map + gwbp_blend_scatter bit for
  * bit in the encoded pixels, hence in every weight and (up to summation order) in F and d. */
-int gwbp_blend_scatter_encoded(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_blend_scatter_encoded(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                                const float *feats, int64_t fs_y, int64_t fs_x, int32_t K, const float *encoder, int32_t n_out,
                                float scale_f, float scale_d, float *F, float *d, float *alphas, void *stream);
 
@@ -155,14 +164,14 @@ int gwbp_blend_scatter_encoded(const gwbp_caps *caps, void *workspace, size_t wo
  * (needs a blend WITHOUT GWBP_FLAG_NARROW_SCATTER).  A caller that overlaps the front stage of view v+1 with the
  * scatter of view v issues it behind the blend on the front's stream and passes d = NULL to gwbp_scatter: the
  * denominators then cost nothing on the scatter's stream (backproject.py:133-150). */
-int gwbp_accumulate_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_accumulate_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                       float scale_d, float *d, void *stream);
 
 /* What the reference obtains through backward(): F[g,:] += scale_f * sum_p w_g(p) * feats[p,:] and
  * d[g] += scale_d * sum_p w_g(p)   (backproject.py:127-131,145-150; scale = 1 for .sum(), 1/(H*W*D) and
  * 1/(H*W*3) for the dino .mean() variant, backproject.py:263,283).  feats is addressed as
  * feats[y*fs_y + x*fs_x + c*fs_c] (strides in floats; D % 128 == 0 or D <= 64 take the fast kernel; fs_c == 1 stages with 16-B loads).  d may be null. */
-int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                  const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c, int32_t D, float scale_f,
                  float scale_d, float *F, float *d, void *stream);
 
@@ -170,7 +179,7 @@ int gwbp_scatter(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
  * (D <= 16, K % 16 == 0, K <= 1024, channel-contiguous 16-B aligned pixels: feats[y*fs_y + x*fs_x + k]) without ever
  * writing the [H,W,D] map: every tile's pixels are read once, full width, and multiplied by the encoder (resident in LDS)
  * on the matrix cores while the tile's slab is staged (exact fp32: v_mfma_f32_16x16x4_f32). */
-int gwbp_scatter_encoded(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_scatter_encoded(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                          const float *feats, int64_t fs_y, int64_t fs_x, int32_t K, const float *encoder, int32_t D,
                          float scale_f, float scale_d, float *F, float *d, void *stream);
 
@@ -179,7 +188,7 @@ int gwbp_scatter_encoded(const gwbp_caps *caps, void *workspace, size_t workspac
  * feats[ymap[y]*fs_y + xmap[x]*fs_x + c*fs_c].  ymap[view.height], xmap[view.width]: int32 device arrays (the host
  * side builds them with PyTorch's nearest rule: min(floor(i * in/out), in-1) in fp32).  Same result as
  * gwbp_scatter on the upsampled map, without ever materialising it. */
-int gwbp_scatter_upsampled(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
+GWBP_API int gwbp_scatter_upsampled(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
                            const gwbp_view *view_host, const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c,
                            int32_t D, const int32_t *ymap, const int32_t *xmap, float scale_f, float scale_d, float *F,
                            float *d, void *stream);
@@ -189,32 +198,32 @@ int gwbp_scatter_upsampled(const gwbp_caps *caps, void *workspace, size_t worksp
  * h0*(w0*L[y0][x0] + w1*L[y0][x1]) + h1*(w0*L[y1][x0] + w1*L[y1][x1]) with y0 = y0map[y], y1 = min(y0+1, lr_h-1),
  * h1 = ly[y], h0 = 1-h1 (same for x): ATen's UpSampleBilinear2d, computed while the tile's slab is staged.  The maps
  * are device arrays of view.height / view.width entries (engine.bilinear_index builds them like ATen does). */
-int gwbp_scatter_bilinear(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_scatter_bilinear(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                           const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c, int32_t D, int32_t lr_h,
                           int32_t lr_w, const int32_t *y0, const float *ly, const int32_t *x0, const float *lx,
                           float scale_f, float scale_d, float *F, float *d, void *stream);
 
 /* Forward render (what rasterization() returns): out[p,:] = sum_g w_g(p) * colors[g,:], out is [H,W,D]. */
-int gwbp_render(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_render(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                 const float *colors, int32_t D, float *out, void *stream);
 
 /* Forward render for 1..32 channels (RGB, RGB+D, depth; round 5: the 16-d compressed field) straight from the sorted tile
  * lists (needs gwbp_project + gwbp_bin_sort of the same view, not the weight store): the render the reference feeds to its
  * 2-D feature network (backproject.py:89-100), compares in utils.test_proper_pruning (utils.py:316-340) and scores per frame
  * in segment_compressed.py:154-165.  alphas[H*W] optional. */
-int gwbp_render_pixels(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_render_pixels(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                        const float *colors, int32_t D, float *out, float *alphas, void *stream);
 
 /* gsplat spherical_harmonics + "+0.5, clamp at 0": coeffs[N,K,3] (K >= (degree+1)^2, degree <= 3), view directions
  * means - campos_host[3]; out[N,3].  What rasterization(..., sh_degree=3) does before rasterising (backproject.py:99). */
-int gwbp_sh_colors(int64_t N, int32_t degree, int32_t K, const float *means, const float *coeffs,
+GWBP_API int gwbp_sh_colors(int64_t N, int32_t degree, int32_t K, const float *means, const float *coeffs,
                    const float *campos_host, float *out, void *stream);
 
 /* ---- fused entry points --------------------------------------------------------------------------------- */
 
 /* project -> bin_sort -> blend_weights -> scatter for one view: the per-view body of
  * create_feature_field_lseg (backproject.py:115-151) in one call, one blend instead of two. */
-int gwbp_backproject_view(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
+GWBP_API int gwbp_backproject_view(const gwbp_caps *caps, void *workspace, size_t workspace_bytes,
                           const gwbp_view *view_host, const float *means, const float *quats, const float *scales,
                           const float *opacities, const float *feats, int64_t fs_y, int64_t fs_x, int64_t fs_c,
                           int32_t D, float scale_f, float scale_d, float *F, float *d, void *stream);
@@ -223,22 +232,22 @@ int gwbp_backproject_view(const gwbp_caps *caps, void *workspace, size_t workspa
  * K % 16 == 0, feats[y*fs_y + x*fs_x + c] (channel-contiguous pixels, 16-B aligned), out [H, W, n_out] dense.  The map is
  * read once at HBM rate; exact fp32 (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain).  workgroups: 0 = as many as
  * stream fastest alone (6.0 TB/s); a caller that overlaps the encoder with latency-bound kernels passes one per CU. */
-int gwbp_encode_map(const float *feats, int64_t fs_y, int64_t fs_x, int32_t height, int32_t width, int32_t K,
+GWBP_API int gwbp_encode_map(const float *feats, int64_t fs_y, int64_t fs_x, int32_t height, int32_t width, int32_t K,
                     const float *encoder, int32_t n_out, float *out, int32_t workgroups, void *stream);
 
 /* backproject.py:63,166-169: out = normalize(F / (1e-12 + d)), NaN -> 0.  out may alias F. */
-int gwbp_finalize(int64_t N, int32_t D, const float *F, const float *d, float *out, void *stream);
+GWBP_API int gwbp_finalize(int64_t N, int32_t D, const float *F, const float *d, float *out, void *stream);
 
 /* Adds this view's counters into `accum` (device, gwbp_stats) -- used by bench/driver to total pairs. */
-int gwbp_accumulate_stats(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, gwbp_stats *accum,
+GWBP_API int gwbp_accumulate_stats(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, gwbp_stats *accum,
                           void *stream);
 /* Copies the workspace's counters of the last view to host memory.  SYNCHRONISES `stream`. */
-int gwbp_read_stats(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, gwbp_stats *stats_host,
+GWBP_API int gwbp_read_stats(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, gwbp_stats *stats_host,
                     void *stream);
 
 /* Debug/test: expand the sparse weight store of the last blended view into triples, sorted by nothing in
  * particular.  gid/pix/w have room for `cap` entries; *n_host receives the count.  SYNCHRONISES. */
-int gwbp_dump_pairs(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+GWBP_API int gwbp_dump_pairs(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                     int64_t cap, int32_t *gid, int32_t *pix, float *w, int64_t *n_host, void *stream);
 
 #ifdef __cplusplus

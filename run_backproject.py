@@ -27,6 +27,15 @@ def main():
     ap.add_argument("--rasterizer", choices=["inria", "gsplat"], default=None, help="deprecated alias of --format")
     ap.add_argument("--data-factor", type=int, default=4)
     ap.add_argument("--feature", choices=["lseg", "dino"], default="lseg")
+    # The reference's main() also takes these two (backproject.py:309-310).  There feature_field_batch_count is handed to
+    # create_feature_field_lseg and never read (backproject.py:25-27,77-82), and run_feature_field_on_cpu only moves the LSeg
+    # NETWORK to the CPU (backproject.py:30-41) -- the rasterisation stays on the GPU either way.  Here the 2-D network is
+    # replaced by supplied feature maps, so both are accepted for command-line compatibility and change nothing.
+    ap.add_argument("--feature-field-batch-count", type=int, default=1,
+                    help="accepted for compatibility with the reference's main() (unused there as well)")
+    ap.add_argument("--run-feature-field-on-cpu", action=argparse.BooleanOptionalAction, default=False,
+                    help="accepted for compatibility: the reference moves only its LSeg network to the CPU with it; the "
+                         "feature maps are supplied here, the back-projection always runs on the GPU")
     ap.add_argument("--feature-maps", default=None, help="directory with <image name>.pt tensors [H,W,D]")
     ap.add_argument("--encoder", default=None, help="[512,16] encoder tensor (.pt): backproject_compressed.py")
     ap.add_argument("--synthetic", default=None, help="run a seeded synthetic config (C1, C2, ...) instead of files")
@@ -38,7 +47,7 @@ def main():
                          "denominators (keep = d > 0), then drop the pruned rows.  Not the reference's arithmetic to the last "
                          "digit: a pruned Gaussian has no weight anywhere but may be the one that TERMINATES pixels "
                          "(T' <= 1e-4), so building with it present moves some kept rows (C2 size, two views: median 7e-9, "
-                         "99 % of the rows within 1.2e-7, 0.4 % beyond 1e-3 of the prune-first result; tests/test_gpu_pruning.py)")
+                         "99 %% of the rows within 1.2e-7, 0.4 %% beyond 1e-3 of the prune-first result; tests/test_gpu_pruning.py)")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend under torchrun (nccl = RCCL over xGMI)")
     ap.add_argument("--one-device", action="store_true",
                     help="every rank uses cuda:0 (with --dist-backend gloo: the N > 1 bookkeeping on a one-GPU box)")

@@ -11,6 +11,12 @@ import gsbp_amd  # noqa: E402,F401  (first thing in the test process: the packag
                  # pipeline needs, which only works before the first HIP call)
 
 
+# DEVELOPER hook of the TEST HARNESS (never of the product, which does not look at the environment to find its library): run the
+# suite against another build of the same C ABI -- tools/alt_build_test.sh builds -O2 / -O1 variants into tools/lib/ and sets this.
+if os.environ.get("GWBP_TEST_LIB"):
+    gsbp_amd._lib.use_library(os.environ["GWBP_TEST_LIB"], allow_profile=True)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

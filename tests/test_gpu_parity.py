@@ -560,6 +560,26 @@ def test_pipelined_driver_equals_serial_driver(dev):
     assert rel_row_err(res[0][0], res[1][0]) <= 1e-5 and np.abs(res[0][1] - res[1][1]).max() <= 1e-4 * res[1][1].max()
 
 
+def test_driver_degrades_to_one_stream_when_the_queue_request_came_late(dev, monkeypatch):
+    """a caller that touched CUDA before `import gsbp_amd` (a notebook, another library) got a hard GwbpError from
+    create_feature_field(pipeline=True) for a concern that only affects speed.  The driver now warns and runs the views on one
+    stream (same F and d); constructing a ViewPipeline explicitly still raises."""
+    from gsbp_amd import _lib
+    cfg, sc = scene_np("T1", n_views=3)
+    d = to_dev(sc, dev)
+    vms = syn.make_cameras(cfg, n_views=3).to(dev)
+    feats_all = [syn.make_feature_map(cfg, v).to(dev) for v in range(3)]
+    args = (d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"], cfg.width, cfg.height, lambda v: feats_all[v],
+            cfg.feat_dim)
+    ref = gsbp_amd.create_feature_field(*args, pipeline=False)
+    monkeypatch.setattr(_lib, "_QUEUES_LATE", True)
+    with pytest.warns(RuntimeWarning, match="ONE stream"):
+        out = gsbp_amd.create_feature_field(*args)
+    assert rel_row_err(out.cpu().numpy(), ref.cpu().numpy()) <= 1e-5
+    with pytest.raises(gsbp_amd.GwbpError, match="GPU_MAX_HW_QUEUES"):
+        gsbp_amd.ViewPipeline(cfg.n_gaussians, cfg.width, cfg.height, dev)
+
+
 def _capture_cases():
     from util import capture_tool
     return capture_tool().CASES
@@ -732,6 +752,31 @@ def test_pipelined_driver_with_the_wide_scatter_kernel(dev, monkeypatch, min_pai
     assert rel_row_err(res[0][0], res[1][0]) <= 1e-5
     assert np.abs(res[0][1] - res[1][1]).max() <= 1e-5 * res[1][1].max()
     assert rel_row_err(res[0][3], res[1][3]) <= 1e-5
+
+
+def test_wide_kernel_selfcheck_and_the_fallback_to_the_narrow_kernel(dev, monkeypatch):
+    """The run-time half of the 256-channel kernel's safety net (VERDICT r5 item 6c): the product library passes the self-check;
+    a library that fails it (simulated verdict) makes the pipeline warn and scatter with the 128-channel kernel -- same field."""
+    from gsbp_amd import backproject as bp
+    bp._WIDE_OK.clear()
+    assert bp.wide_kernel_selfcheck(dev) is True and len(bp._WIDE_OK) == 1
+    cfg, sc = scene_np("T1", n_views=4)
+    d = to_dev(sc, dev)
+    D = 256
+    vms = syn.make_cameras(cfg, n_views=4).to(dev)
+    feats_all = [syn.make_feature_map(cfg, v, dim=D).to(dev) for v in range(4)]
+    args = (d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"], cfg.width, cfg.height, lambda v: feats_all[v], D)
+    pipe = gsbp_amd.ViewPipeline(cfg.n_gaussians, cfg.width, cfg.height, dev, scatter_dim=D)
+    assert pipe.wide is True
+    ref = gsbp_amd.create_feature_field(*args)
+    for k in list(bp._WIDE_OK):
+        monkeypatch.setitem(bp._WIDE_OK, k, False)
+    with pytest.warns(RuntimeWarning, match="128-channel"):
+        pipe = gsbp_amd.ViewPipeline(cfg.n_gaussians, cfg.width, cfg.height, dev, scatter_dim=D)
+    assert pipe.wide is False
+    with pytest.warns(RuntimeWarning, match="128-channel"):
+        out = gsbp_amd.create_feature_field(*args)
+    assert rel_row_err(out.cpu().numpy(), ref.cpu().numpy()) <= 1e-5
 
 
 @pytest.mark.parametrize("pipeline", [True, False], ids=["pipelined", "serial"])
@@ -1028,15 +1073,19 @@ def test_non_finite_features_reach_exactly_the_gaussians_that_touch_them(orc, de
 
 def test_profile_build_of_the_wide_kernel_agrees_with_the_narrow_one(dev):
     """k_scatter_wide keeps asm-issued loads in flight across compiler-visible code; a build with a different register allocation
-    (PROFILE + in-kernel stamps) once copied two landing registers in front of their wait.  When the PROFILE library has been
-    built (make -C <pkg>/csrc PROFILE=1 -> tools/lib/libgwbp_profile.so), run the wide-vs-narrow comparison on it in a child
-    process (one library per process); skipped otherwise."""
+    (PROFILE + in-kernel stamps) once copied two landing registers in front of their wait.  The PROFILE library is built from
+    the SAME sources as the product library (`_lib.build_profile()`: by __graft_entry__.build() in the container, by this test
+    where hipcc exists; a library older than the sources FAILS instead of being tested) and the wide-vs-narrow comparison runs
+    on it in a child process (one library per process)."""
     import subprocess
     import sys
+    from gsbp_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "tools", "lib", "libgwbp_profile.so")
-    if not os.path.exists(lib):
-        pytest.skip("PROFILE library not built")
+    lib = _lib.PROFILE_LIB_PATH
+    if os.path.exists("/opt/rocm/bin/hipcc"):
+        _lib.build_profile()
+    assert os.path.exists(lib), "tools/lib/libgwbp_profile.so missing: __graft_entry__.build() makes it"
+    assert not _lib._stale(lib), "tools/lib/libgwbp_profile.so is older than csrc/: rebuild (python __graft_entry__.py)"
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "wide_vs_narrow.py"), lib], capture_output=True, text=True,
                        timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -26,15 +26,16 @@ def test_two_ranks_on_one_gpu_match_single_process(dev):
     assert "TWO_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def _bench(*extra):
+def _bench(*extra, config="C1", warmup="2", gpus="2"):
     """`python3 bench.py --gpus 2 ...` started as a PLAIN process, the way the driver runs --gpus 1: bench.py itself must
     start the two fresh ranks (before any GPU call) and relay rank 0's JSON line."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C1", "--warmup", "2",
-                        "--no-cpu-baseline", "--dist-backend", "gloo", "--one-device", *extra],
+    dist_args = ["--dist-backend", "gloo", "--one-device"] if gpus != "1" else []
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", gpus, "--config", config, "--warmup", warmup,
+                        "--no-cpu-baseline", *dist_args, *extra],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -99,3 +100,35 @@ def test_bench_one_rank_over_rccl(dev):
     assert j["exchange_ms"] > 0 and j["checked"]["ok"] is True
     assert j["scaling"] == "strong" and j["config"]["total_views"] == 8 and j["steps"] == 8
     assert [d["steps"] for d in j["dist"]["devices"]] == [8]
+
+
+def test_c3_workload_two_ranks_at_full_size(dev):
+    """BASELINE.json configs[2] ("C3": the C2 workload -- 1 M Gaussians, 1600x1060, D = 512 -- sharded by view over the GPUs) AT ITS
+    OWN SIZE in the driver-run suite (the two-rank tests above run C1-size scenes).  Two fresh ranks share the one GPU
+    over gloo: not RCCL over xGMI, but the view sharding, the 2 GB reduce-scatter of F on the padded storage, the all-reduce of d,
+    the row-local result check on the REDUCED rows, and -- in strong mode -- the same 6 views giving the same pair count as one
+    rank, all at full size."""
+    j2 = _bench("--total-views", "6", config="C2", warmup="1")
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and j2["config"]["total_views"] == 6
+    assert j2["dist"]["world_size"] == 2 and j2["dist"]["backend"] == "gloo"
+    assert sorted(d["steps"] for d in j2["dist"]["devices"]) == [3, 3]
+    assert j2["checked"]["ok"] is True and j2["config"]["overflow"] == 0
+    assert "1000000 Gaussians, 1600x1060 views, D=512" in j2["config"]["workload"]
+    # F [1 M, 512] fp32 (+ d): 2.05 GB leave every rank in the one exchange step
+    assert j2["dist"]["exchange_bytes_per_rank"] == 1_000_000 * 512 * 4 + 1_000_000 * 4
+    assert j2["exchange_ms"] > 0
+    j1 = _bench("--total-views", "6", config="C2", warmup="1", gpus="1")
+    assert j1["dist"] is None and j1["steps"] == 6 and j1["checked"]["ok"] is True
+    pairs1 = j1["config"]["pairs_per_view"] * 6
+    pairs2 = j2["value"] * (j2["ms_per_step"] * 1e-3 * j2["steps"]) / 512  # value = pairs x D / elapsed
+    assert abs(pairs1 - pairs2) <= 1e-6 * pairs1, (pairs1, pairs2)
+
+
+def test_bench_refuses_more_ranks_than_gpus(dev):
+    """`bench.py --gpus N` on a node with fewer than N GPUs exits non-zero with a one-line message instead of hanging in
+    init_process_group (unless --one-device asks for the one-GPU bookkeeping check)."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and f"--gpus {n}" in (r.stderr + r.stdout) and "GPU(s)" in (r.stderr + r.stdout)
