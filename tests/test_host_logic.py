@@ -147,6 +147,12 @@ def test_bench_starts_its_own_ranks_for_gpus_n(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--total-views", "9"])
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
+    # fewer GPUs than ranks: a one-line refusal, nothing is launched (round 6: no hang in init_process_group)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "--gpus 4" in str(e.value.code) and "2 GPU(s)" in str(e.value.code) and not seen
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 7
