@@ -40,7 +40,15 @@ constexpr int kBatch = 64;
 //            results land -- after a 4 x 4 exchange between the rows of 16 lanes -- in the registers kFused loads them into.
 //            No [H, W, 16] map, no encoder kernel, and the HBM stream of one wave's prologue overlaps with the other waves'
 //            blend loops on the same SIMD instead of two kernels competing for wave slots.
-enum BlendMode { kStore = 0, kHalves = 1, kFused = 2, kFusedEnc = 3 };
+//   kToken:  NO store either, for a LOW-RESOLUTION map that the reference upsamples with F.interpolate(mode="nearest") and whose
+//            texels ("tokens": the dino variant's 64 x 64 patch tokens, backproject.py:242-249) are at least a tile wide and high:
+//            a tile then sees at most 2 x 2 tokens, and F_v[g, :] = sum_p w_g(p) feats[p, :] = sum_t omega_{g,t} tok[t, :] with
+//            omega_{g,t} = sum_{p in t} w_g(p).  A contributing record turns into its FOUR token-quadrant weight sums, written
+//            as one 16-B line at the record's EMIT position (k_emit wrote the intersections of a Gaussian contiguously, in the
+//            order of its tile rectangle; estart[gid] is where they start) -- so the weight sums of one Gaussian lie back to back
+//            whatever tiles they came from, and k_token_apply (token.hip) adds them to F with ONE plain read-modify-write of the
+//            row per view: no pair entries, no headers, no atomics, no slabs, no carry rows.
+enum BlendMode { kStore = 0, kHalves = 1, kFused = 2, kFusedEnc = 3, kToken = 4 };
 constexpr int kFusedCh = 16;
 constexpr int kEncWaves = 8;    // kFusedEnc: tiles (waves) per workgroup sharing one LDS copy of the encoder
 constexpr int kEncMaxK = 512;   // ... whose K x 16 floats take at most 32 KB
@@ -54,7 +62,36 @@ struct FusedArgs { // kFused only
     float *F;
     const float *enc; // kFusedEnc: [enc_k, D] row-major; feats then has enc_k channels per pixel
     int enc_k;
+    // kToken only
+    const int32_t *ymap, *xmap; // nearest-upsampling index maps (view.height / view.width entries): pixel -> token row / column
+    float *omega;               // [isect_cap][4]: weight sums per (emit position, token quadrant qx | qy << 1), zeroed per view
+    const u32 *estart;          // first emit position of every Gaussian (k_emit)
+    const uint2 *rect;          // the tile rectangle the emit walked (k_project)
 };
+
+// Sums of FOUR per-lane values over the 64 lanes, transposed: every lane l returns the wave total of value (l & 3).
+// xor-1 and xor-2 exchanges halve the register count (each side keeps the values whose index bit matches its lane bit and adds
+// the partner's copy), two row rotations by multiples of four add the quads of a row, two lane swaps add the four rows: 15
+// vector instructions where four full reductions take about 50.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float mask_select(u64 mask, float a, float b);
+__device__ __forceinline__ float rows_sum(float v);
+__device__ __forceinline__ float transposed_sum4(float v0, float v1, float v2, float v3)
+{
+    const u64 odd = 0xAAAAAAAAAAAAAAAAull, upper2 = 0xCCCCCCCCCCCCCCCCull; // lanes with bit 0 / bit 1 set
+    // stage 1 (i <-> i ^ 1): even lanes keep v0, v2, odd lanes v1, v3
+    const float k0 = mask_select(odd, v1, v0) + dpp_mov<0xB1>(mask_select(odd, v0, v1));
+    const float k1 = mask_select(odd, v3, v2) + dpp_mov<0xB1>(mask_select(odd, v2, v3));
+    // stage 2 (i <-> i ^ 2): lanes with bit 1 clear keep k0 (values 0, 1), the others k1 (values 2, 3)
+    float r = mask_select(upper2, k1, k0) + dpp_mov<0x4E>(mask_select(upper2, k0, k1));
+    r += dpp_mov<0x124>(r); // row_ror:4
+    r += dpp_mov<0x128>(r); // row_ror:8: all four quads of the row
+    return rows_sum(r);
+}
 
 // Sum of 16 per-lane values over the 64 lanes, transposed: lane l returns the wave total of value c(l),
 //   c(l) = bit2(l) | bit3(l) << 1 | bit0(l) << 2 | bit1(l) << 3        (the same in all four rows of 16 lanes).
