@@ -50,7 +50,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 EXPORTS = [
     "gwbp_version", "gwbp_last_error_string", "gwbp_workspace_size", "gwbp_project", "gwbp_bin_sort",
-    "gwbp_blend_weights", "gwbp_blend_weights_d", "gwbp_blend_scatter", "gwbp_blend_scatter_encoded", "gwbp_accumulate_d", "gwbp_scatter", "gwbp_scatter_encoded", "gwbp_scatter_upsampled", "gwbp_scatter_bilinear", "gwbp_render", "gwbp_render_pixels", "gwbp_sh_colors",
+    "gwbp_blend_weights", "gwbp_blend_weights_d", "gwbp_blend_scatter", "gwbp_blend_scatter_encoded", "gwbp_blend_tokens", "gwbp_scatter_tokens", "gwbp_accumulate_d", "gwbp_scatter", "gwbp_scatter_encoded", "gwbp_scatter_upsampled", "gwbp_scatter_bilinear", "gwbp_render", "gwbp_render_pixels", "gwbp_sh_colors",
     "gwbp_backproject_view", "gwbp_encode_map", "gwbp_finalize",
     "gwbp_accumulate_stats", "gwbp_read_stats", "gwbp_dump_pairs",
 ]
@@ -136,6 +136,8 @@ ARGTYPES = {
     "gwbp_blend_weights_d": _WSV + [_P, _F, _P, _P],
     "gwbp_blend_scatter": _WSV + [_P, _I64, _I64, _I32, _F, _F, _P, _P, _P, _P],
     "gwbp_blend_scatter_encoded": _WSV + [_P, _I64, _I64, _I32, _P, _I32, _F, _F, _P, _P, _P, _P],
+    "gwbp_blend_tokens": _WSV + [_P, _P, _P, _P],
+    "gwbp_scatter_tokens": _WSV + [_P, _I64, _I64, _I32, _P, _P, _F, _F, _P, _P, _P],
     "gwbp_accumulate_d": _WSV + [_F, _P, _P],
     "gwbp_scatter": _WSV + _MAP + [_F, _F, _P, _P, _P],
     "gwbp_scatter_encoded": _WSV + [_P, _I64, _I64, _I32, _P, _I32, _F, _F, _P, _P, _P],

@@ -170,8 +170,13 @@ class ViewPipeline:
     def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None,
                  allow_wide: bool = True, scatter_workgroups: Optional[int] = None, side_priority: int = -1,
                  front_priority: Optional[bool] = None, fuse_small: bool = True, side_streams: Optional[int] = None,
-                 view_per_stream: Optional[bool] = None):
+                 view_per_stream: Optional[bool] = None, token_grid=None):
         self.dev = torch.device(device)
+        # token_grid = (h, w): the views' feature maps are h x w maps upsampled with mode="nearest" whose texels are at least a
+        # tile wide and high (the dino variant's 64 x 64 patch tokens): the front stage ends with Engine.blend_tokens (per-record
+        # token-quadrant weight sums instead of a weight store) and scatter() runs Engine.scatter_tokens -- one plain
+        # read-modify-write of every F row that receives weight, no atomics (csrc/token.hip)
+        self.token_grid = tuple(int(x) for x in token_grid) if token_grid is not None else None
         from . import _lib
         if _lib.hw_queues_late():
             # the schedule below is built on streams that run CONCURRENTLY; with the HIP runtime's default of 4 hardware queues
@@ -205,7 +210,7 @@ class ViewPipeline:
         small_image = Engine.fused_max_dim(width, height) == Engine.FUSED_MAX_DIM_SMALL
         # view_per_stream=True: large images too run every view entirely on a stream of its own (K > 2 workspaces): the fused
         # kernels of consecutive views then overlap at their edges (measured for the compressed variant)
-        self.fuse_small = (bool(fuse_small) and scatter_dim is not None
+        self.fuse_small = (bool(fuse_small) and scatter_dim is not None and self.token_grid is None
                            and scatter_dim <= Engine.fused_max_dim(width, height)
                            and (small_image or len(self.eng) == 2 or bool(view_per_stream)))
         self.front_priority = front_priority  # None: raised wave priority for the front exactly when the wide kernel runs
@@ -250,7 +255,8 @@ class ViewPipeline:
         are pending: every Engine remembers whether the view in its workspace was blended with the half-tile lists, and
         scatters a view blended without them through the 128-channel kernel (front() likewise recorded whether it has
         already added that view's denominators)."""
-        wide = self.allow_wide and self.scatter_dim is not None and self.scatter_dim % 256 == 0
+        wide = (self.allow_wide and self.scatter_dim is not None and self.scatter_dim % 256 == 0
+                and self.token_grid is None)  # (token space: neither scatter kernel runs)
         if wide and n_pairs is not None and n_headers:
             wide = n_pairs / n_headers >= self.WIDE_MIN_PAIRS_PER_RECORD
         if wide and self.dev.type == "cuda" and not wide_kernel_selfcheck(self.dev):
@@ -282,18 +288,20 @@ class ViewPipeline:
             e = self.eng[b]
             e.project(view, means, quats, scales, opacities)
             e.bin_sort(view)
-            self.pending[self.i_front] = (view, False, False)
+            self.pending[self.i_front] = (view, False, False, False)
             self.i_front += 1
             return
         with torch.cuda.stream(side):
             e = self.eng[b]
             e.project(view, means, quats, scales, opacities)
             e.bin_sort(view)
-            d_done = d is not None and self.wide and not self.fuse_small
-            if not self.fuse_small:
+            d_done = d is not None and self.wide and not self.fuse_small and self.token_grid is None
+            if self.token_grid is not None:
+                e.blend_tokens(view, *self.token_grid)
+            elif not self.fuse_small:
                 e.blend_weights(view, d=d if d_done else None, scale_d=scale_d)
             self.ev_front[b].record(side)
-        self.pending[self.i_front] = (view, d_done, not self.fuse_small)
+        self.pending[self.i_front] = (view, d_done, not self.fuse_small, self.token_grid is not None)
         self.i_front += 1
 
     # Encoder workgroups per CU beside the pipeline (see encode_ahead): None = 1 next to the separate blend and small-D
@@ -362,9 +370,19 @@ class ViewPipeline:
         e = self.eng[b]
         if t0 is not None:
             t0.record(main)
-        view, d_done, blended = self.pending.pop(i)
+        view, d_done, blended, tok = self.pending.pop(i)
         fused = not blended and encoder is None and upsample is None and Engine.can_blend_scatter(feats)
-        if fused:
+        if tok:
+            if (upsample == "nearest" and encoder is None and tuple(feats.shape[:2]) == self.token_grid
+                    and Engine.can_scatter_tokens(feats, view.height, view.width)):
+                e.scatter_tokens(view, feats, F, d, scale_f, scale_d)
+            else:  # this view's map does not suit the token path after all: blend a weight store here, then the usual scatter
+                e.blend_weights(view)
+                if encoder is not None:
+                    e.scatter_encoded(view, feats, encoder, F, d, scale_f, scale_d)
+                else:
+                    e.scatter(view, feats, F, d, scale_f, scale_d, upsample=upsample)
+        elif fused:
             e.blend_scatter(view, feats, F, d, scale_f, scale_d)
         elif not blended and encoder is not None and upsample is None and Engine.can_blend_scatter_encoded(feats, encoder):
             # the compressed variant in ONE kernel: encoder in the tile prologue, then blend + scatter from registers
@@ -488,7 +506,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                          return_partials: bool = False, verbose: bool = False, upsample: Optional[str] = None,
                          gather: bool = True, allow_wide: bool = True, fuse_encoder: bool = False,
                          fuse_small: bool = True, feature_fn_stream_safe: bool = False,
-                         encoder_in_blend: Optional[bool] = None):
+                         encoder_in_blend: Optional[bool] = None, token_space: bool = True):
     """Build the [N, dim_out] per-Gaussian feature field.
 
     means/quats/scales/opacities: post-activation Gaussians (backproject.py:55-57), device tensors.
@@ -510,6 +528,11 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     one kernel per view, no [H,W,dim_out] map, four views in flight on streams of their own).  None (default) = whenever the
     first map's layout allows and fuse_small is on (C5: 1.27-1.33 against 1.38-1.44 ms/view for the encoder one view ahead);
     False = never.
+    token_space: with upsample="nearest", maps whose texels are at least a 16 x 16 tile wide and high and whose channel count is a
+    multiple of 256 (the dino variant's 64 x 64 x 1024 patch tokens at 1600 x 1060) are back-projected in TOKEN space: the blend
+    leaves per-(Gaussian, tile) weight sums of the tile's 2 x 2 tokens and every F row that receives weight is updated with ONE
+    plain read-modify-write per view from the L2-resident token map -- no atomics, no weight store (csrc/token.hip).  False keeps
+    the pixel-slab kernels (gwbp_scatter_upsampled) for such maps too.
     fuse_small: maps of at most 16 channels (after the encoder) are blended AND scattered by one kernel
     (gwbp_blend_scatter: no weight store, no scatter kernel; C5 1.96 -> 1.42 ms/view); False keeps the two-kernel form.
     feature_fn_stream_safe: STREAM CONTRACT of feature_fn.  False (default): feature_fn runs on the caller's current stream
@@ -559,12 +582,16 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                 pipeline = False
         for attempt in range(6):  # a capacity overflow invalidates the accumulators: grow the workspace, start over
             if pipeline and len(my_views) > 1:
-                first_map = feature_fn(my_views[0]) if encoder is not None else None
+                first_map = feature_fn(my_views[0]) if (encoder is not None or upsample == "nearest") else None
+                # the dino shape -- a nearest-upsampled map whose texels are at least a tile wide and high, D % 256 == 0 -- goes
+                # through token space (Engine.blend_tokens / scatter_tokens); decided on the first map, checked per view
+                token_grid = (tuple(first_map.shape[:2]) if (token_space and upsample == "nearest" and encoder is None
+                                                             and Engine.can_scatter_tokens(first_map, height, width)) else None)
                 enc_blend = (encoder is not None and fuse_small and not fuse_encoder and upsample is None
                              and encoder_in_blend is not False and Engine.can_blend_scatter_encoded(first_map, encoder))
                 depth = (pipeline_depth(n, width, height, d_out, encoder_in_blend=enc_blend) if pipeline is True
                          else max(2, int(pipeline)))
-                pipe = ViewPipeline(n, width, height, dev, scatter_dim=d_out,
+                pipe = ViewPipeline(n, width, height, dev, scatter_dim=d_out, token_grid=token_grid,
                                     allow_wide=allow_wide, fuse_small=fuse_small and not (fuse_encoder and encoder is not None),
                                     view_per_stream=True if (enc_blend and depth > 2) else None,
                                     engines=[eng] + [Engine(n, width, height, device=dev, tight_binning=eng.tight_binning,
@@ -621,6 +648,8 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                         # (view-per-stream schedule: the feature function runs on the stream that consumes its map)
                         with torch.cuda.stream(pipe.scatter_stream()):
                             feats, after = feature_fn(v), None
+                    elif upsample == "nearest" and i == 0:
+                        feats, after = first_map, None  # (already produced to read its shape)
                     else:
                         feats, after = feature_fn(v), None  # on the caller's stream; scatter() waits for it with an event
                     pipe.scatter(feats, F, d, sf, sd, upsample=upsample, after=after,
@@ -641,6 +670,11 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                         eng.blend_scatter(view, feats, F, d, sf, sd)
                     elif upsample is None:
                         eng.backproject_view(view, means, quats, scales, opacities, feats, F, d, sf, sd)
+                    elif token_space and upsample == "nearest" and Engine.can_scatter_tokens(feats, height, width):
+                        eng.project(view, means, quats, scales, opacities)
+                        eng.bin_sort(view)
+                        eng.blend_tokens(view, feats.shape[0], feats.shape[1])
+                        eng.scatter_tokens(view, feats, F, d, sf, sd)
                     else:
                         eng.project(view, means, quats, scales, opacities)
                         eng.bin_sort(view)
@@ -648,6 +682,9 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                         eng.scatter(view, feats, F, d, sf, sd, upsample=upsample)
                     eng.accumulate_stats(accum)
                 stats = Engine.decode_stats(accum)  # synchronises
+            if stats["overflow"] & 8:
+                raise RuntimeError("gwbp_blend_tokens met a tile that spans more than 2 x 2 texels (gwbp_stats.overflow bit 3): "
+                                   "the map is finer than Engine.token_geometry_ok() admitted")
             if stats["overflow"] & 4:
                 raise RuntimeError("a view was scattered with a kernel that did not match its blend (gwbp_stats.overflow "
                                    "bit 2): F and d are incomplete")

@@ -69,29 +69,6 @@ struct FusedArgs { // kFused only
     const uint2 *rect;          // the tile rectangle the emit walked (k_project)
 };
 
-// Sums of FOUR per-lane values over the 64 lanes, transposed: every lane l returns the wave total of value (l & 3).
-// xor-1 and xor-2 exchanges halve the register count (each side keeps the values whose index bit matches its lane bit and adds
-// the partner's copy), two row rotations by multiples of four add the quads of a row, two lane swaps add the four rows: 15
-// vector instructions where four full reductions take about 50.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float x)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float mask_select(u64 mask, float a, float b);
-__device__ __forceinline__ float rows_sum(float v);
-__device__ __forceinline__ float transposed_sum4(float v0, float v1, float v2, float v3)
-{
-    const u64 odd = 0xAAAAAAAAAAAAAAAAull, upper2 = 0xCCCCCCCCCCCCCCCCull; // lanes with bit 0 / bit 1 set
-    // stage 1 (i <-> i ^ 1): even lanes keep v0, v2, odd lanes v1, v3
-    const float k0 = mask_select(odd, v1, v0) + dpp_mov<0xB1>(mask_select(odd, v0, v1));
-    const float k1 = mask_select(odd, v3, v2) + dpp_mov<0xB1>(mask_select(odd, v2, v3));
-    // stage 2 (i <-> i ^ 2): lanes with bit 1 clear keep k0 (values 0, 1), the others k1 (values 2, 3)
-    float r = mask_select(upper2, k1, k0) + dpp_mov<0x4E>(mask_select(upper2, k0, k1));
-    r += dpp_mov<0x124>(r); // row_ror:4
-    r += dpp_mov<0x128>(r); // row_ror:8: all four quads of the row
-    return rows_sum(r);
-}
 
 // Sum of 16 per-lane values over the 64 lanes, transposed: lane l returns the wave total of value c(l),
 //   c(l) = bit2(l) | bit3(l) << 1 | bit0(l) << 2 | bit1(l) << 3        (the same in all four rows of 16 lanes).
@@ -182,6 +159,28 @@ __device__ __forceinline__ float mask_select(u64 mask, float a, float b)
     return r;
 }
 
+// Sums of FOUR per-lane values over the 64 lanes, transposed: every lane l returns the wave total of value (l & 3).
+// xor-1 and xor-2 exchanges halve the register count (each side keeps the values whose index bit matches its lane bit and adds
+// the partner's copy), two row rotations by multiples of four add the quads of a row, two lane swaps add the four rows: 15
+// vector instructions where four full reductions take about 50.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float transposed_sum4(float v0, float v1, float v2, float v3)
+{
+    const u64 odd = 0xAAAAAAAAAAAAAAAAull, upper2 = 0xCCCCCCCCCCCCCCCCull; // lanes with bit 0 / bit 1 set
+    // stage 1 (i <-> i ^ 1): even lanes keep v0, v2, odd lanes v1, v3
+    const float k0 = mask_select(odd, v1, v0) + dpp_mov<0xB1>(mask_select(odd, v0, v1));
+    const float k1 = mask_select(odd, v3, v2) + dpp_mov<0xB1>(mask_select(odd, v2, v3));
+    // stage 2 (i <-> i ^ 2): lanes with bit 1 clear keep k0 (values 0, 1), the others k1 (values 2, 3)
+    float r = mask_select(upper2, k1, k0) + dpp_mov<0x4E>(mask_select(upper2, k0, k1));
+    r += dpp_mov<0x124>(r); // row_ror:4
+    r += dpp_mov<0x128>(r); // row_ror:8: all four quads of the row
+    return rows_sum(r);
+}
+
 // One 8-B store per lane whose bit is set in `mask`: exec IS the ballot mask.  (`if ((mask >> lane) & 1)` makes the compiler
 // rebuild the predicate per lane: two v_and, a 64-bit compare and a saveexec per quarter.)
 __device__ __forceinline__ void store_pair_masked(u64 mask, WPair *dst, const WPair &e)
@@ -236,13 +235,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
 #endif
     constexpr bool WSUM = MODE == kHalves; // the record's weight sum in its header (+ d[gid] right here)
     constexpr bool FUSED = MODE == kFused || MODE == kFusedEnc;
+    constexpr bool TOKEN = MODE == kToken;
     front_priority(prio);
     __shared__ float4 s_a_[WAVES][kBatch]; // mx, my, opac, gid bits
     __shared__ float4 s_b_[WAVES][kBatch]; // ca, cb, cc, strip mask
     __shared__ float s_thr_[WAVES][kBatch]; // ln(255 o) + margin: sigma above this cannot reach alpha >= 1/255
+    __shared__ u32 s_pos_[TOKEN ? WAVES : 1][TOKEN ? kBatch : 1]; // kToken: emit position of the (Gaussian, tile) pair
     const int wave = WAVES > 1 ? (int)uniform(threadIdx.x >> 6) : 0;
     float4 *const s_a = s_a_[wave], *const s_b = s_b_[wave];
     float *const s_thr = s_thr_[wave];
+    u32 *const s_pos = s_pos_[TOKEN ? wave : 0];
 
     const int n_tiles_all = V.tile_w * V.tile_h;
     const int slot = (int)blockIdx.x * WAVES + wave;
@@ -285,6 +287,26 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     }
     u32 page_pos = 0, page_left = 0, npairs = 0, hdr_n = 0, span_n = 0; // wave-uniform
     bool dead = false;                                     // wave-uniform: pool exhausted
+
+    // kToken: which of the tile's (at most) 2 x 2 tokens a pixel falls into, as lane masks: cmask = lanes whose column lies in the
+    // tile's SECOND token column, rmask[q] = lanes whose row 4 q + lane / 16 lies in its second token row.  The nearest index maps
+    // are non-decreasing; a tile that spans more than two token columns or rows (texels narrower than a tile) violates the entry
+    // point's precondition and raises overflow bit 3 -- the host never takes this path for such maps.
+    u64 cmask = 0ull, rmask[4] = {0ull, 0ull, 0ull, 0ull};
+    if constexpr (TOKEN) {
+        const int c_rel = fu.xmap[min(ix, V.W - 1)] - fu.xmap[min(tx * kTile, V.W - 1)];
+        cmask = __ballot(c_rel >= 1);
+        bool wide = c_rel > 1 || c_rel < 0;
+        const int r_base = fu.ymap[min(ty * kTile, V.H - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r_rel = fu.ymap[min(iy0 + 4 * q, V.H - 1)] - r_base;
+            rmask[q] = __ballot(r_rel >= 1);
+            wide |= r_rel > 1 || r_rel < 0;
+        }
+        if (__ballot(wide) != 0ull && lane == 0)
+            atomicOr(&ctr->overflow, kOverflowTokenGeometry);
+    }
 
     // kFused: the lane's four pixels, kFusedCh channels each, stay in registers for the whole tile (pixels outside the
     // image never get a weight: T = 0; they read a clamped address)
@@ -464,6 +486,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             s_b[lane] = make_float4(b.x, b.y, b.z, __int_as_float((int)smask));
             // alpha = o exp(-sigma) >= 1/255  <=>  sigma <= ln(255 o); 1e-3 absorbs the error of __logf and exp_neg
             s_thr[lane] = L + 1e-3f;
+            if constexpr (TOKEN) { // this (Gaussian, tile) pair's emit position: k_emit walked the rectangle row-major from estart
+                const uint2 rc = fu.rect[gid];
+                const u32 rx0 = rc.x & 0xFFFFu, rx1 = rc.x >> 16, ry0 = rc.y & 0xFFFFu;
+                s_pos[lane] = fu.estart[gid] + ((u32)ty - ry0) * (rx1 - rx0) + ((u32)tx - rx0);
+            }
         }
         // single wave: LDS operations of one wave complete in program order, no barrier needed
 
@@ -527,6 +554,24 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
                 }
                 base[q] = total;
                 total += cnt[q];
+            }
+            if constexpr (TOKEN) {
+                // the record's four token-quadrant weight sums (index qx | qy << 1), one 16-B line at its emit position
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (m[q] != 0ull) { // wave-uniform
+                        const float wq = mask_select(m[q], w[q], 0.f);
+                        a1 += mask_select(rmask[q], wq, 0.f);
+                        a0 += mask_select(rmask[q], 0.f, wq);
+                    }
+                const float r = transposed_sum4(mask_select(cmask, 0.f, a0), mask_select(cmask, a0, 0.f),
+                                                mask_select(cmask, 0.f, a1), mask_select(cmask, a1, 0.f));
+                if (!(dbg & 1) && lane < 4)
+                    fu.omega[(size_t)s_pos[j] * 4 + lane] = r;
+                ++hdr_n;
+                npairs += total;
+                continue;
             }
             if constexpr (FUSED) {
                 float p[kFusedCh], wl = 0.f;
@@ -624,9 +669,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
         }
     }
     if (lane == 0) {
-        if (FUSED && slot == 0)
-            ctr->blend_kind = kBlendFused; // (no k_pool_stats launch behind the fused kernel: the pool is untouched)
-        hdr_count[tile] = FUSED ? 0u : hdr_n; // kFused: the store stays empty
+        if ((FUSED || TOKEN) && slot == 0)
+            ctr->blend_kind = TOKEN ? kBlendToken : kBlendFused; // (no k_pool_stats launch behind these: the pool is untouched)
+        hdr_count[tile] = (FUSED || TOKEN) ? 0u : hdr_n; // kFused / kToken: the store stays empty
         if (hdr_n)
             atomicAdd(&ctr->n_headers, hdr_n);
         if (npairs)
@@ -924,6 +969,27 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
         hipLaunchKernelGGL(k_pool_stats, dim3(1), dim3(1), 0, s, W.shards, W.counters,
                            (L.flags & GWBP_FLAG_NARROW_SCATTER) ? 0u : kBlendHalves);
     return check_hip(hipGetLastError(), "blend launch");
+}
+
+// gwbp_blend_tokens: the blend whose product is the per-(Gaussian, tile) token-quadrant weight sums (k_blend<kToken>) in the
+// workspace's header region (16 of its 64 B per intersection), zeroed for this view's intersections first.
+int launch_blend_tokens(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, const int32_t *ymap, const int32_t *xmap,
+                        hipStream_t s)
+{
+    if (!ymap || !xmap)
+        return set_error(GWBP_EINVAL, "gwbp_blend_tokens needs both index maps");
+    int rc = launch_zero_omega(L, W, s);
+    if (rc)
+        return rc;
+    FusedArgs fu = {};
+    fu.ymap = ymap, fu.xmap = xmap, fu.omega = reinterpret_cast<float *>(W.headers), fu.estart = W.dkeys[1], fu.rect = W.rect;
+    const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
+    const int n_tiles = V.tile_w * V.tile_h;
+    const int fin = sort_passes(n_tiles) & 1;
+    const int ablate = profile_knob("GWBP_ABLATE_BLEND");
+    hipLaunchKernelGGL(k_blend<kToken>, dim3(n_tiles), dim3(64), 0, s, V, W.tile_offsets, W.vals[fin], W.g2d, W.counters, W.headers,
+                       W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, W.tile_order, alphas, ablate, prio, nullptr, 0.f, fu);
+    return check_hip(hipGetLastError(), "blend_tokens launch");
 }
 
 int launch_dump_pairs(const Layout &L, const Ws &W, const ViewDev &V, int64_t cap, int32_t *gid, int32_t *pix,

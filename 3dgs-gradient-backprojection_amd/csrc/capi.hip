@@ -220,9 +220,9 @@ extern "C" {
 const char *gwbp_version(void)
 {
 #ifdef GWBP_PROFILE
-    return "libgwbp gfx950 r5 (PROFILE build: ablation knobs live, results may be invalid)";
+    return "libgwbp gfx950 r6 (PROFILE build: ablation knobs live, results may be invalid)";
 #else
-    return "libgwbp gfx950 r5";
+    return "libgwbp gfx950 r6";
 #endif
 }
 const char *gwbp_last_error_string(void) { return g_err; }
@@ -336,6 +336,35 @@ int gwbp_blend_scatter_encoded(const gwbp_caps *caps, void *workspace, size_t wo
     FeatMap M{feats, fs_y, fs_x, 1, nullptr, nullptr, nullptr, nullptr, 0, 0};
     M.enc = encoder, M.enc_k = K;
     return launch_blend(L, W, V, alphas, d, scale_d, static_cast<hipStream_t>(stream), &M, n_out, scale_f, F);
+}
+
+int gwbp_blend_tokens(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                      const int32_t *ymap, const int32_t *xmap, float *alphas, void *stream)
+{
+    Layout L;
+    Ws W;
+    ViewDev V;
+    int rc = bind_workspace(caps, workspace, workspace_bytes, &L, &W);
+    if (rc)
+        return rc;
+    if ((rc = make_view(view_host, caps, &V)))
+        return rc;
+    return launch_blend_tokens(L, W, V, alphas, ymap, xmap, static_cast<hipStream_t>(stream));
+}
+
+int gwbp_scatter_tokens(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                        const float *tokens, int64_t ts_y, int64_t ts_x, int32_t D, const int32_t *ymap, const int32_t *xmap,
+                        float scale_f, float scale_d, float *F, float *d, void *stream)
+{
+    Layout L;
+    Ws W;
+    ViewDev V;
+    int rc = bind_workspace(caps, workspace, workspace_bytes, &L, &W);
+    if (rc)
+        return rc;
+    if ((rc = make_view(view_host, caps, &V)))
+        return rc;
+    return launch_token_apply(L, W, V, tokens, ts_y, ts_x, D, ymap, xmap, scale_f, scale_d, F, d, static_cast<hipStream_t>(stream));
 }
 
 int gwbp_accumulate_d(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,

@@ -79,7 +79,9 @@ struct Counters {
 };
 constexpr u32 kBlendHalves = 1u;
 constexpr u32 kBlendFused = 2u; // gwbp_blend_scatter: the view was blended AND scattered, its weight store is empty
+constexpr u32 kBlendToken = 3u; // gwbp_blend_tokens: the workspace holds per-(Gaussian, tile) token-quadrant weight sums, no store
 constexpr u32 kOverflowMismatch = 4u; // gwbp_stats::overflow bit 2, see include/gwbp.h
+constexpr u32 kOverflowTokenGeometry = 8u; // bit 3: gwbp_blend_tokens met a tile that spans more than 2 x 2 tokens
 static_assert(sizeof(Counters) == sizeof(gwbp_stats), "Counters must mirror gwbp_stats");
 
 struct Layout {
@@ -152,6 +154,12 @@ struct FeatMap;
 // M != nullptr: the fused small-D form (gwbp_blend_scatter): F[gid, :D] and d are accumulated by the blend itself
 int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, float *d, float scale_d, hipStream_t s,
                  const FeatMap *M = nullptr, int D = 0, float scale_f = 1.0f, float *F = nullptr);
+// token-space path of a nearest-upsampled low-resolution map (blend.hip: k_blend<kToken>; token.hip)
+int launch_blend_tokens(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, const int32_t *ymap, const int32_t *xmap,
+                        hipStream_t s);
+int launch_zero_omega(const Layout &L, const Ws &W, hipStream_t s);
+int launch_token_apply(const Layout &L, const Ws &W, const ViewDev &V, const float *tokens, int64_t ts_y, int64_t ts_x, int D,
+                       const int32_t *ymap, const int32_t *xmap, float scale_f, float scale_d, float *F, float *d, hipStream_t s);
 // A 2-D feature map as the scatter kernels address it: feats[row(y)*fs_y + col(x)*fs_x + c*fs_c] (strides in floats).
 // ymap/xmap (device, optional) send an output pixel to the row/column of a lower-resolution map: the
 // F.interpolate(mode="nearest") of backproject.py:244-248 without materialising the upsampled map.  With ly/lx as well

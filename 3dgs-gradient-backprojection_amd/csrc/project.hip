@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kScanBlock) void k_emit(int64_t N, int tile_w, cons
                                                      const u32 *__restrict__ touched,
                                                      const u32 *__restrict__ blocksums,
                                                      const Counters *__restrict__ ctr, u32 *__restrict__ keys,
-                                                     u32 *__restrict__ vals, int prio)
+                                                     u32 *__restrict__ vals, u32 *__restrict__ estart, int prio)
 {
     front_priority(prio);
     if (ctr->overflow & 1u)
@@ -290,6 +290,10 @@ __global__ __launch_bounds__(kScanBlock) void k_emit(int64_t N, int tile_w, cons
     if (cnt == 0)
         return;
     u32 pos = blocksums[blockIdx.x] + woff + incl - cnt;
+    // where this Gaussian's intersections start: they are written contiguously, row-major over its tile rectangle, so a consumer
+    // that knows (gid, tile) finds the emit position by arithmetic -- k_blend<kToken> files its per-record weight sums there and
+    // k_token_apply reads a Gaussian's sums back to back (token.hip)
+    estart[gid] = pos;
     const uint2 rc = rect[gid];
     const u32 x0 = rc.x & 0xFFFFu, x1 = rc.x >> 16, y0 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
     for (u32 ty = y0; ty < y1; ++ty)
@@ -308,7 +312,7 @@ int launch_emit(const Layout &L, const Ws &W, const ViewDev &V, const u32 *order
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(kSumThreads), 0, s, L.n_scan_blocks, W.blocksums, W.counters,
                        (u32)L.isect_cap, prio);
     hipLaunchKernelGGL(k_emit, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, V.tile_w, order, W.rect, W.touched,
-                       W.blocksums, W.counters, W.keys[0], W.vals[0], prio);
+                       W.blocksums, W.counters, W.keys[0], W.vals[0], W.dkeys[1], prio);
     return check_hip(hipGetLastError(), "emit launch");
 }
 
@@ -317,7 +321,7 @@ int launch_emit_scanned(const Layout &L, const Ws &W, const ViewDev &V, const u3
 {
     const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
     hipLaunchKernelGGL(k_emit, dim3(L.n_scan_blocks), dim3(kScanBlock), 0, s, L.n, V.tile_w, order, W.rect, W.touched,
-                       W.blocksums, W.counters, W.keys[0], W.vals[0], prio);
+                       W.blocksums, W.counters, W.keys[0], W.vals[0], W.dkeys[1], prio);
     return check_hip(hipGetLastError(), "emit launch");
 }
 

@@ -1,0 +1,205 @@
+// token.hip -- the scatter of a NEAREST-UPSAMPLED low-resolution map in TOKEN space (dino variant, backproject.py:242-289).
+//
+// The reference upsamples the network's 64 x 64 x 1024 patch-token map to the view's 1600 x 1060 pixels with
+// F.interpolate(mode="nearest") (backproject.py:244-248) and back-projects the 6.9 GB result.  Every pixel of a token carries the
+// same vector, so
+//     F_v[g, :] = sum_p w_g(p) feats[p, :] = sum_t omega_{g,t} tok[t, :],     omega_{g,t} = sum_{p in t} w_g(p),
+// and when a token is at least a tile wide and high a 16 x 16 tile sees at most 2 x 2 of them: k_blend<kToken> (blend.hip) reduces
+// every contributing (Gaussian, tile) record to FOUR weight sums and files them at the record's EMIT position.  k_emit wrote the
+// intersections of one Gaussian contiguously (row-major over its tile rectangle, Gaussians in depth order), so here one wave
+// walks a Gaussian's sums back to back, multiplies them with token rows and adds the result to F[g, :] with ONE plain
+// read-modify-write per view -- the formulation "whose partial sums are combined on chip across tiles" that the full-resolution
+// path cannot have, available because the D-wide operand is a 16 MB table instead of a 6.9 GB map:
+// no atomics, no weight store, no slabs, no carry rows, no sort by Gaussian.
+//
+// HBM traffic per view: 8 B x D per Gaussian that receives weight (C2 geometry, D = 1024: 0.53 M rows -> 4.4 GB) + the 16-B sums
+// (0.06 GB); the token rows (about five 4-KB rows per touched Gaussian) come from L2 / Infinity Cache.
+//
+// XCD-aware work map: the channels are cut into 256-channel chunks and a workgroup's chunk is its XCD class (blockIdx % 8)
+// modulo the chunk count, so each XCD's 4 MB L2 keeps re-reading the SAME 256-channel slice of the token map (64 x 64 tokens x 1 KB
+// = 4 MB at D = 1024) while the F rows stream past it with non-temporal loads and stores.
+#include "gwbp_dev.h"
+
+namespace gwbp {
+
+constexpr int kTokCh = 256;       // channels per wave pass: one float4 per lane
+constexpr int kTokPerWave = 16;   // Gaussians (consecutive in depth order) per wave
+constexpr int kTokWaves = 4;
+constexpr int kTokGroup = kTokPerWave * kTokWaves; // Gaussians per workgroup
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_zero_omega(float4 *__restrict__ omega, const Counters *__restrict__ ctr, int prio)
+{
+    front_priority(prio);
+    const u32 n = ctr->n_isect;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+        omega[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+struct TokenApplyArgs {
+    int64_t N;
+    const u32 *order;   // Gaussians in depth order (the emit order)
+    const u32 *touched; // emit slots per Gaussian (0 = culled)
+    const u32 *estart;  // first emit slot
+    const uint2 *rect;  // tile rectangle of the emit
+    const float *omega; // [n_isect][4]
+    const int32_t *ymap, *xmap;
+    const float *tokens; // tokens[row * ts_y + col * ts_x + c]
+    int64_t ts_y, ts_x;
+    int D, n_chunks, W, H;
+    float scale_f, scale_d;
+    float *F, *d;
+    Counters *ctr;
+};
+
+__global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A)
+{
+    if (A.ctr->blend_kind != kBlendToken) { // the view in this workspace was not blended by gwbp_blend_tokens
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            atomicOr(&A.ctr->overflow, kOverflowMismatch);
+        return;
+    }
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)uniform(threadIdx.x >> 6);
+    // chunk = XCD class modulo the chunk count when that divides 8 (1, 2, 4, 8 chunks); any other count: plain interleave
+    u32 chunk, group;
+    if (8 % A.n_chunks == 0) {
+        const u32 xcd = blockIdx.x & 7u, per = 8u / (u32)A.n_chunks;
+        chunk = xcd % (u32)A.n_chunks;
+        group = (blockIdx.x >> 3) * per + xcd / (u32)A.n_chunks;
+    } else {
+        chunk = blockIdx.x % (u32)A.n_chunks;
+        group = blockIdx.x / (u32)A.n_chunks;
+    }
+    const int64_t i0 = (int64_t)group * kTokGroup + wave * kTokPerWave;
+    if (i0 >= A.N)
+        return;
+    // lanes 0..15: the wave's Gaussians
+    u32 m_gid = 0, m_cnt = 0, m_es = 0, m_rx = 0, m_ry = 0;
+    if (lane < kTokPerWave && i0 + lane < A.N) {
+        m_gid = A.order[i0 + lane];
+        m_cnt = A.touched[m_gid];
+        if (m_cnt) {
+            m_es = A.estart[m_gid];
+            const uint2 rc = A.rect[m_gid];
+            m_rx = rc.x, m_ry = rc.y;
+        }
+    }
+    const u64 live = __ballot(m_cnt != 0u);
+    if (live == 0ull)
+        return;
+    const int quad = lane & 3, sl = lane >> 2; // lane = (slot within a batch of 16, token quadrant qx | qy << 1)
+    const size_t coff = (size_t)chunk * kTokCh + (size_t)lane * 4;
+    for (u64 rest = live; rest != 0ull; rest &= rest - 1) {
+        const int k = __ffsll((long long)rest) - 1;
+        const u32 gid = (u32)__builtin_amdgcn_readlane((int)m_gid, k), cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k);
+        const u32 es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
+        const u32 rx = (u32)__builtin_amdgcn_readlane((int)m_rx, k), ry = (u32)__builtin_amdgcn_readlane((int)m_ry, k);
+        const u32 x0 = rx & 0xFFFFu, rw = (rx >> 16) - x0, y0 = ry & 0xFFFFu;
+        float *frow = A.F + (size_t)gid * (size_t)A.D + coff;
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        float dsum = 0.f;
+        bool any = false; // wave-uniform: some sum of this Gaussian is non-zero
+        f4 fold = {0.f, 0.f, 0.f, 0.f};
+        for (u32 s0 = 0; s0 < cnt; s0 += 16u) {
+            const u32 slot = s0 + (u32)sl;
+            const float om = slot < cnt ? A.omega[(size_t)(es + slot) * 4 + quad] : 0.f; // 256 contiguous bytes per batch
+            const u64 nz = __ballot(om != 0.f);
+            if (nz == 0ull)
+                continue;
+            if (!any) { // first weight of this Gaussian: start the row's read now, it lands under the token reads
+                any = true;
+                fold = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(frow));
+            }
+            dsum += om;
+            // the token under this lane's (tile, quadrant): first token of the tile + (qx, qy); only dereferenced where om != 0,
+            // i.e. where the blend found a pixel of that token
+            const u32 ty = y0 + slot / rw, tx = x0 + slot % rw;
+            const int tc = A.xmap[min((int)(tx * kTile), A.W - 1)] + (quad & 1);
+            const int tr = A.ymap[min((int)(ty * kTile), A.H - 1)] + (quad >> 1);
+            const long long toff = (long long)tr * A.ts_y + (long long)tc * A.ts_x;
+            const int tlo = (int)(u32)toff, thi = (int)(toff >> 32);
+            u64 todo = nz;
+            while (todo != 0ull) { // four entries' rows in flight
+                f4 t[4];
+                float w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    w[u] = 0.f;
+                    t[u] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (todo != 0ull) { // wave-uniform
+                        const int l = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(om), l));
+                        const long long o = ((long long)__builtin_amdgcn_readlane(thi, l) << 32) |
+                                            (long long)(u32)__builtin_amdgcn_readlane(tlo, l);
+                        t[u] = *reinterpret_cast<const f4 *>(A.tokens + o + (long long)coff);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (w[u] != 0.f) { // (wave-uniform; a skipped slot must not turn 0 x NaN into NaN)
+                        acc.x = __builtin_fmaf(w[u], t[u].x, acc.x);
+                        acc.y = __builtin_fmaf(w[u], t[u].y, acc.y);
+                        acc.z = __builtin_fmaf(w[u], t[u].z, acc.z);
+                        acc.w = __builtin_fmaf(w[u], t[u].w, acc.w);
+                    }
+            }
+        }
+        if (!any)
+            continue; // visible, binned, but no pixel with weight: F and d keep their values (nothing is read or written)
+        fold.x = __builtin_fmaf(A.scale_f, acc.x, fold.x);
+        fold.y = __builtin_fmaf(A.scale_f, acc.y, fold.y);
+        fold.z = __builtin_fmaf(A.scale_f, acc.z, fold.z);
+        fold.w = __builtin_fmaf(A.scale_f, acc.w, fold.w);
+        __builtin_nontemporal_store(fold, reinterpret_cast<f4 *>(frow));
+        if (chunk == 0 && A.d) { // one wave per Gaussian owns d[gid] as well: plain read-modify-write
+            const float tot = wave_sum(dsum);
+            if (lane == 0)
+                A.d[gid] = __builtin_fmaf(A.scale_d, tot, A.d[gid]);
+        }
+    }
+}
+
+int launch_zero_omega(const Layout &L, const Ws &W, hipStream_t s)
+{
+    const int prio = (L.flags & GWBP_FLAG_FRONT_PRIORITY) ? 1 : 0;
+    hipLaunchKernelGGL(k_zero_omega, dim3(1024), dim3(256), 0, s, reinterpret_cast<float4 *>(W.headers), W.counters, prio);
+    return check_hip(hipGetLastError(), "zero_omega launch");
+}
+
+int launch_token_apply(const Layout &L, const Ws &W, const ViewDev &V, const float *tokens, int64_t ts_y, int64_t ts_x, int D,
+                       const int32_t *ymap, const int32_t *xmap, float scale_f, float scale_d, float *F, float *d, hipStream_t s)
+{
+    if (D < kTokCh || D % kTokCh != 0)
+        return set_error(GWBP_EUNSUPPORTED, "gwbp_scatter_tokens: D must be a multiple of %d (got %d); use gwbp_scatter_upsampled", kTokCh,
+                         D);
+    if (!tokens || !ymap || !xmap || (L.n > 0 && !F))
+        return set_error(GWBP_EINVAL, "gwbp_scatter_tokens: null tokens / index maps / F");
+    if (ts_y < 0 || ts_x < D || (ts_y & 3) || (ts_x & 3) || (reinterpret_cast<uintptr_t>(tokens) & 15) ||
+        (reinterpret_cast<uintptr_t>(F) & 15))
+        return set_error(GWBP_EINVAL, "gwbp_scatter_tokens: token rows must be 16-B aligned runs of D contiguous channels "
+                                      "(strides %lld %lld), F 16-B aligned", (long long)ts_y, (long long)ts_x);
+    if (L.n == 0)
+        return GWBP_OK;
+    TokenApplyArgs A;
+    A.N = L.n, A.order = W.dvals[0], A.touched = W.touched, A.estart = W.dkeys[1], A.rect = W.rect;
+    A.omega = reinterpret_cast<const float *>(W.headers);
+    A.ymap = ymap, A.xmap = xmap, A.tokens = tokens, A.ts_y = ts_y, A.ts_x = ts_x;
+    A.D = D, A.n_chunks = D / kTokCh, A.W = V.W, A.H = V.H, A.scale_f = scale_f, A.scale_d = scale_d, A.F = F, A.d = d;
+    A.ctr = W.counters;
+    const int64_t n_groups = (L.n + kTokGroup - 1) / kTokGroup;
+    int64_t blocks;
+    if (8 % A.n_chunks == 0) {
+        const int per = 8 / A.n_chunks;
+        blocks = ((n_groups + per - 1) / per) * 8;
+    } else {
+        blocks = n_groups * A.n_chunks;
+    }
+    if (blocks > 0x7FFFFFFFll)
+        return set_error(GWBP_EINVAL, "gwbp_scatter_tokens: grid too large");
+    hipLaunchKernelGGL(k_token_apply, dim3((unsigned)blocks), dim3(64 * kTokWaves), 0, s, A);
+    return check_hip(hipGetLastError(), "token_apply launch");
+}
+
+} // namespace gwbp

@@ -73,6 +73,7 @@ class Engine:
         # because meta["isect_ids"] of the drop-in operator must show gsplat's 3-sigma binning
         self.tight_binning = bool(tight_binning)
         self._halves = False  # the workspace holds the half-tile lists + weight sums of the view blended last
+        self._tokens = None   # (h, w) of the map whose token-quadrant weight sums the workspace holds (blend_tokens)
         self.stream, self._stream_handle = None, None
         self._alloc()
 
@@ -181,6 +182,7 @@ class Engine:
         """d (optional, float32[N]): also add this view's denominators d[g] += scale_d * sum_p w_g(p) from inside the blend
         (gwbp_blend_weights_d; needs the 256-channel scatter kernel enabled, like accumulate_d)."""
         alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
+        self._tokens = None
         self._halves = self._wide_requested()  # k_blend<HALVES> writes the lists only without NARROW_SCATTER
         if d is not None:
             if d.dtype != torch.float32 or not d.is_cuda or d.shape != (self.n,) or not d.is_contiguous():
@@ -223,7 +225,7 @@ class Engine:
         sy, sx, _, D = self._feat_strides(feats, view)
         self._check_acc(F, d, D)
         alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
-        self._halves = False  # the store is empty: no scatter kernel has anything to read
+        self._halves, self._tokens = False, None  # the store is empty: no scatter kernel has anything to read
         self._call("gwbp_blend_scatter", *self._args(), C.byref(view), ptr(feats), sy, sx, D, C.c_float(scale_f),
                    C.c_float(scale_d), ptr(F), ptr(d), ptr(alphas), self._stream())
         return alphas
@@ -258,7 +260,7 @@ class Engine:
         self._check_acc(F, d, n)
         enc = encoder.contiguous()
         alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
-        self._halves = False  # the store is empty: no scatter kernel has anything to read
+        self._halves, self._tokens = False, None  # the store is empty: no scatter kernel has anything to read
         self._call("gwbp_blend_scatter_encoded", *self._args(), C.byref(view), ptr(feats), sy, sx, K, ptr(enc), n,
                    C.c_float(scale_f), C.c_float(scale_d), ptr(F), ptr(d), ptr(alphas), self._stream())
         return alphas
@@ -273,6 +275,70 @@ class Engine:
         if min(sy, sx, sc) < 0:
             raise GwbpError("negative feature-map strides are not supported")
         return sy, sx, sc, feats.shape[2]
+
+    # ---- token space: the dino variant's nearest-upsampled patch-token map (backproject.py:242-249) ------------------
+    TOKEN_CHUNK = 256  # gwbp_scatter_tokens walks the channels in chunks of 256 (one float4 per lane)
+
+    _TOKEN_GEOMETRY: Dict[Tuple[int, int, int, int], bool] = {}
+
+    @classmethod
+    def token_geometry_ok(cls, lr_h: int, lr_w: int, height: int, width: int) -> bool:
+        """Does every 16 x 16 tile of a height x width view see at most 2 x 2 texels of an lr_h x lr_w map under
+        F.interpolate(mode="nearest")?  Checked on the exact index maps (PyTorch's fp32 rule), tile by tile: the precondition
+        of gwbp_blend_tokens.  True whenever a texel is at least a tile wide and high (the 64 x 64 dino tokens at 1600 x 1060)."""
+        key = (int(lr_h), int(lr_w), int(height), int(width))
+        ok = cls._TOKEN_GEOMETRY.get(key)
+        if ok is None:
+            ok = True
+            for n_in, n_out in ((key[0], key[2]), (key[1], key[3])):
+                m = nearest_index(n_in, n_out).to(torch.int64)
+                first = m[0::TILE]
+                last = m[torch.clamp(torch.arange(0, n_out, TILE) + TILE - 1, max=n_out - 1)]
+                ok = ok and int((last - first).max()) <= 1
+            cls._TOKEN_GEOMETRY[key] = ok
+        return ok
+
+    @classmethod
+    def can_scatter_tokens(cls, tokens: torch.Tensor, height: int, width: int) -> bool:
+        """Low-resolution maps the token-space path takes: [h, w, D] float32 on the device, D % 256 == 0, channel-contiguous
+        16-B aligned rows, and texels at least a tile wide and high (token_geometry_ok)."""
+        if tokens.dim() != 3 or not tokens.is_cuda or tokens.dtype != torch.float32:
+            return False
+        sy, sx, sc = tokens.stride()
+        D = tokens.shape[2]
+        return (D >= cls.TOKEN_CHUNK and D % cls.TOKEN_CHUNK == 0 and sc == 1 and sy % 4 == 0 and sx % 4 == 0 and sy >= 0
+                and sx >= D and tokens.data_ptr() % 16 == 0
+                and cls.token_geometry_ok(tokens.shape[0], tokens.shape[1], int(height), int(width)))
+
+    def blend_tokens(self, view, lr_h: int, lr_w: int, want_alphas=False):
+        """blend_weights for a view whose feature map is an lr_h x lr_w map upsampled with mode="nearest" (the dino variant):
+        instead of a weight store the blend leaves, per contributing (Gaussian, tile) record, the weight sums of the tile's
+        2 x 2 tokens (gwbp_blend_tokens); scatter_tokens() consumes them.  Same weights, same alpha map."""
+        if not self.token_geometry_ok(lr_h, lr_w, view.height, view.width):
+            raise GwbpError(f"blend_tokens: a {lr_h}x{lr_w} map has texels narrower than a tile at {view.height}x{view.width}; "
+                            "use blend_weights + scatter(upsample='nearest')")
+        ymap, xmap = self.nearest_maps(lr_h, lr_w, view.height, view.width)
+        alphas = torch.empty(view.height, view.width, device=self.device) if want_alphas else None
+        self._halves = False  # no weight store: only scatter_tokens can consume this view
+        self._tokens = (int(lr_h), int(lr_w))
+        self._call("gwbp_blend_tokens", *self._args(), C.byref(view), ptr(ymap), ptr(xmap), ptr(alphas), self._stream())
+        return alphas
+
+    def scatter_tokens(self, view, tokens, F, d, scale_f=1.0, scale_d=1.0):
+        """F[g,:] += scale_f * sum_t omega_{g,t} tokens[t,:], d[g] += scale_d * sum_t omega_{g,t} from the sums blend_tokens left:
+        equals scatter(view, tokens, F, d, upsample="nearest") up to summation order, with one plain read-modify-write of every
+        row that receives weight (no atomics: deterministic) and the token map read from L2 / Infinity Cache."""
+        if getattr(self, "_tokens", None) != (int(tokens.shape[0]), int(tokens.shape[1])):
+            raise GwbpError("scatter_tokens needs blend_tokens(view, h, w) of the same view and map size first")
+        if not self.can_scatter_tokens(tokens, view.height, view.width):
+            raise GwbpError(f"scatter_tokens: [h,w,D] float32 map with D % 256 == 0, channel-contiguous 16-B aligned rows and texels "
+                            f"of at least a tile required, got {tuple(tokens.shape)} strides {tuple(tokens.stride())}")
+        D = tokens.shape[2]
+        self._check_acc(F, d, D)
+        ymap, xmap = self.nearest_maps(tokens.shape[0], tokens.shape[1], view.height, view.width)
+        sy, sx, _ = tokens.stride()
+        self._call("gwbp_scatter_tokens", *self._args(), C.byref(view), ptr(tokens), C.c_int64(sy), C.c_int64(sx), D, ptr(ymap),
+                   ptr(xmap), C.c_float(scale_f), C.c_float(scale_d), ptr(F), ptr(d), self._stream())
 
     def accumulate_d(self, view, d, scale_d=1.0):
         """d += scale_d * sum_p w from the blend's per-record weight sums (needs a blend with the wide scatter enabled)."""
@@ -312,6 +378,9 @@ class Engine:
         upsample="nearest" / "bilinear": feats is a LOW-RESOLUTION map [h,w,D]; the result equals scattering
         F.interpolate(feats, size=(H,W), mode=...) (dino: backproject.py:244-248; lseg: backproject.py:110-112,
         align_corners=False) without building that map -- the interpolation happens while the tile slabs are staged."""
+        if self._tokens is not None:
+            raise GwbpError("this view was blended with blend_tokens (no weight store): scatter_tokens() is its consumer; "
+                            "blend_weights() first for scatter()")
         if self._wide_requested() and not self._halves:
             # This view was blended WITH GWBP_FLAG_NARROW_SCATTER (no half-tile lists): the 256-channel kernel would read
             # another view's tables.  Scatter it with the 128-channel kernel, which needs only the headers every blend writes.
@@ -432,7 +501,7 @@ class Engine:
         self._check_acc(F, d, D)
         means, quats = _req(means, "means", (3,)), _req(quats, "quats", (4,))
         scales, opacities = _req(scales, "scales", (3,)), _req(opacities, "opacities")
-        self._halves = self._wide_requested()
+        self._halves, self._tokens = self._wide_requested(), None
         self._call("gwbp_backproject_view", *self._args(), C.byref(view), ptr(means), ptr(quats), ptr(scales),
                                              ptr(opacities), ptr(feats), C.c_int64(sy), C.c_int64(sx),
                                              C.c_int64(sc), D, C.c_float(scale_f), C.c_float(scale_d), ptr(F),

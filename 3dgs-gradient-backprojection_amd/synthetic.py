@@ -30,6 +30,11 @@ class Config:
     log_scale0: float  # median scale s0 (world units)
     garden: bool  # 70 % volume + 30 % ground disc
     encoder_dim: Optional[int] = None  # backproject_compressed.py: 512 -> 16
+    # the 2-D network's OWN map shape, where the reference upsamples it to the view (None: the map is given at view resolution)
+    lowres: Optional[tuple] = None     # (h, w) of the network map
+    upsample: Optional[str] = None     # "nearest" (dino, backproject.py:244-248) | "bilinear" (lseg, backproject.py:110-112)
+    reduction: str = "sum"             # "sum" (lseg, backproject.py:127,145) | "mean" (dino, backproject.py:263,283)
+    normalize: bool = True             # L2-normalise over channels (lseg, backproject.py:109); dino's patch tokens are not
 
 
 # BASELINE.json "configs" in order (C3 = C2 sharded over ranks).
@@ -38,6 +43,12 @@ CONFIGS: Dict[str, Config] = {
     "C2": Config("C2", 1_000_000, 200, 1600, 1060, 512, 0.004, True),
     "C4": Config("C4", 5_000_000, 300, 1600, 1060, 768, 0.002, True),
     "C5": Config("C5", 1_000_000, 200, 1600, 1060, 512, 0.004, True, encoder_dim=16),
+    # The reference's feature maps AS THE REFERENCE PRODUCES THEM, at C2 geometry (a1 / a7 "as the reference runs them"):
+    # dino: 64 x 64 x 1024 patch tokens, nearest-upsampled, .mean() reductions (backproject.py:201,242-249,263,283)
+    "DINO64": Config("DINO64", 1_000_000, 200, 1600, 1060, 1024, 0.004, True, lowres=(64, 64), upsample="nearest",
+                     reduction="mean", normalize=False),
+    # lseg: 480 x 480 x 512 normalised map, bilinearly upsampled, .sum() reductions (backproject.py:102-113,127,145)
+    "LSEG480": Config("LSEG480", 1_000_000, 200, 1600, 1060, 512, 0.004, True, lowres=(480, 480), upsample="bilinear"),
     # small shapes used by the parity tests and smoke()
     "T0": Config("T0", 512, 2, 96, 64, 8, 0.06, False),
     "T1": Config("T1", 4_000, 2, 200, 136, 24, 0.04, True),
@@ -108,12 +119,26 @@ def make_cameras(cfg: Config, seed: int = CAMERA_SEED, n_views: Optional[int] = 
 
 
 def make_feature_map(cfg: Config, view: int, device="cpu", dim: Optional[int] = None) -> torch.Tensor:
-    """[H,W,D] fp32, N(0,1) then L2-normalised over D (mimics backproject.py:109); seed = 10000 + view."""
+    """[H,W,D] fp32, N(0,1) then L2-normalised over D (mimics backproject.py:109); seed = 10000 + view.  Configs with a
+    `lowres` shape return the network's own [h,w,D] map (what the reference upsamples to the view)."""
     d = cfg.feat_dim if dim is None else dim
     g = torch.Generator(device=device).manual_seed(FEATURE_SEED0 + view)
-    f = torch.randn(cfg.height, cfg.width, d, generator=g, device=device)
-    f /= f.norm(dim=-1, keepdim=True)
+    h, w = cfg.lowres if cfg.lowres else (cfg.height, cfg.width)
+    f = torch.randn(h, w, d, generator=g, device=device)
+    if cfg.normalize:
+        f /= f.norm(dim=-1, keepdim=True)
     return f
+
+
+def upsample_map(cfg: Config, low: torch.Tensor) -> torch.Tensor:
+    """The reference's own upsampling of a network map to the view ([h,w,D] -> [H,W,D]): F.interpolate(mode=cfg.upsample)
+    (backproject.py:110-112 bilinear, align_corners=False; :244-248 nearest).  Used by checks and the CPU baseline, which
+    back-project the materialised map like the reference does."""
+    if cfg.upsample is None:
+        return low
+    kw = {"align_corners": False} if cfg.upsample == "bilinear" else {}
+    up = torch.nn.functional.interpolate(low.permute(2, 0, 1)[None], size=(cfg.height, cfg.width), mode=cfg.upsample, **kw)
+    return up[0].permute(1, 2, 0)
 
 
 def make_encoder(cfg: Config, seed: int = ENCODER_SEED) -> torch.Tensor:

@@ -7,7 +7,9 @@ step    : one view of the hot path: project -> bin/sort -> blend weights -> scat
           (backproject.py:115-151), inputs resident in HBM.  Views shard over ranks (r, r+R, ...); after the last
           step the ranks' partial F/d are summed with ONE all-reduce (RCCL over xGMI) inside the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C1|C4|C5] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C1|C4|C5|DINO64|LSEG480] [--no-cpu-baseline]
+      (DINO64 / LSEG480: the C2 scene with the reference's feature maps AS IT PRODUCES THEM -- 64x64x1024 dino patch tokens,
+       nearest-upsampled, .mean() reductions; the 480x480x512 lseg map, bilinearly upsampled -- backproject.py:242-249, :102-113)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -79,6 +81,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
     ap.add_argument("--exact-binning", action="store_true",
                     help="gsplat's 3-sigma tile binning instead of GWBP_FLAG_TIGHT_BINNING (same F and d either way)")
+    ap.add_argument("--token-space", choices=("on", "off"), default="on",
+                    help="DINO64: nearest-upsampled maps whose texels cover a tile go through token space (gwbp_blend_tokens + "
+                         "gwbp_scatter_tokens: no atomics); off = the pixel-slab kernels with index maps (gwbp_scatter_upsampled)")
     ap.add_argument("--no-fuse-small", action="store_true",
                     help="D <= 16: keep blend (weight store) and scatter as two kernels instead of gwbp_blend_scatter")
     ap.add_argument("--total-views", type=int, default=0,
@@ -160,7 +165,13 @@ def main():
     D = cfg.encoder_dim or D_in
 
     # feature-map pool, generated on device (seeded), L2-normalised over channels like backproject.py:109
+    # (configs with a `lowres` shape: the pool holds the network's own [h,w,D] maps, upsampled inside the kernels)
     pool = [syn.make_feature_map(cfg, 1000 * rank + i, device=dev) for i in range(args.pool)]
+    up = cfg.upsample
+    # reduction="mean" (dino, backproject.py:263,283): the kernels take the two scale factors
+    sf, sd = (1.0 / (H * W * D), 1.0 / (H * W * 3)) if cfg.reduction == "mean" else (1.0, 1.0)
+    token_grid = (tuple(cfg.lowres) if (up == "nearest" and args.token_space == "on" and encoder is None
+                                        and gsbp_amd.Engine.can_scatter_tokens(pool[0], H, W)) else None)
     tight = not args.exact_binning
     eng = gsbp_amd.Engine(N, W, H, device=dev, tight_binning=tight, isect_cap=args.isect_cap)
     F, d, F_store = gsbp_amd.backproject.alloc_accumulators(N, D, dev, world)
@@ -168,8 +179,14 @@ def main():
 
     # capacity check on one untimed view (the timed loop never reads sizes back)
     while True:
-        eng.backproject_view(views[0], means, quats, scales, opac, pool[0] if encoder is None else pool[0] @ encoder,
-                             F, d)
+        if up is None:
+            eng.backproject_view(views[0], means, quats, scales, opac, pool[0] if encoder is None else pool[0] @ encoder,
+                                 F, d)
+        else:
+            eng.project(views[0], means, quats, scales, opac)
+            eng.bin_sort(views[0])
+            eng.blend_weights(views[0])
+            eng.scatter(views[0], pool[0], F, d, sf, sd, upsample=up)
         st = eng.stats()
         if not st["overflow"]:
             break
@@ -187,7 +204,8 @@ def main():
                                      scatter_workgroups=args.pipe_wgs, side_priority=args.side_prio,
                                      front_priority=None if args.front_prio == "auto" else args.front_prio == "on",
                                      fuse_small=not args.no_fuse_small, side_streams=args.side_streams,
-                                     view_per_stream=True if (args.view_per_stream or (enc_blend and depth > 2)) else None)
+                                     view_per_stream=True if (args.view_per_stream or (enc_blend and depth > 2)) else None,
+                                     token_grid=token_grid)
         accum = pipe.accum
         if args.enc_wgs_per_cu:
             pipe.ENCODER_WORKGROUPS_PER_CU = args.enc_wgs_per_cu
@@ -205,7 +223,7 @@ def main():
             if 0 <= k < args.steps:
                 ev[k][0].record(pipe.stream_of(pipe.i_front))
             st_front = pipe.stream_of(pipe.i_front)
-            pipe.front(views[i], means, quats, scales, opac, d)  # d: added behind the blend when the wide kernel is used
+            pipe.front(views[i], means, quats, scales, opac, d, sd)  # d: added behind the blend when the wide kernel is used
             if 0 <= k < args.steps:
                 ev[k][1].record(st_front)
 
@@ -241,21 +259,26 @@ def main():
                 if 0 <= k < args.steps:
                     ev[k][3].record()
                 return
-            eng.blend_weights(views[i])
+            if token_grid is not None:
+                eng.blend_tokens(views[i], *token_grid)
+            else:
+                eng.blend_weights(views[i])
             if 0 <= k < args.steps:
                 ev[k][2].record()
             if fenc is not None:
                 eng.scatter_encoded(views[i], feats, fenc, F, d)
+            elif token_grid is not None:
+                eng.scatter_tokens(views[i], feats, F, d, sf, sd)
             else:
-                eng.scatter(views[i], feats, F, d)
+                eng.scatter(views[i], feats, F, d, sf, sd, upsample=up)
             eng.accumulate_stats(accum)
             if 0 <= k < args.steps:
                 ev[k][3].record()
             return
         timed = 0 <= k < args.steps
         # ready: the maps come from a pool built (and synchronised) before the timed region
-        pipe.scatter(feats, F, d, t0=ev[k][2] if timed else None, t1=ev[k][3] if timed else None, after=after,
-                     encoder=fenc, ready=encoder is None)
+        pipe.scatter(feats, F, d, sf, sd, t0=ev[k][2] if timed else None, t1=ev[k][3] if timed else None, after=after,
+                     encoder=fenc, ready=encoder is None, upsample=up)
 
     def run_views(lo, hi):
         """Views lo..hi-1 through the two-deep pipeline; every front and every scatter of the range is enqueued here."""
@@ -326,7 +349,7 @@ def main():
     if not args.no_check:
         # (d itself holds the all-reduced denominators of ALL Gaussians; d_sum is this rank's row block of it)
         checked = check_results(args, gsbp_amd, eng, views, (means, quats, scales, opac), pool, encoder, F_rows, d,
-                                row0, use_dist, dist, dev)
+                                row0, use_dist, dist, dev, cfg, syn, sf, sd)
 
     stats = pipe.stats() if pipe is not None else gsbp_amd.Engine.decode_stats(accum)
     tt = torch.tensor([elapsed, float(stats["n_pairs"]), float(stats["overflow"]), exchange_ms, float(args.steps)],
@@ -368,7 +391,11 @@ def main():
         # (encoder inside the kernel: the dominant kernel reads the FULL-width map once, SURVEY.md 8(d) "plus 3.47 GB if the
         # 512-d map is read and encoded on the fly")
         d_read = D_in if (encoder is not None and args.encoder in ("blend", "fused")) else D
-        b_scatter = 4.0 * H * W * d_read + 8.0 * n_vis * (D + 1)
+        # (a low-resolution network map is read at ITS size: the materialised [H,W,D] map the survey's formula prices -- 6.9 GB for
+        # dino -- is the reference's intermediate, not an input; `survey_formula_bytes` reports that figure beside it)
+        map_px = float(cfg.lowres[0] * cfg.lowres[1]) if cfg.lowres else float(H * W)
+        b_scatter = 4.0 * map_px * d_read + 8.0 * n_vis * (D + 1)
+        b_survey = 4.0 * H * W * d_read + 8.0 * n_vis * (D + 1)
         b_view = b_scatter + 44.0 * N + 24.0 * n_isect
         achieved = b_scatter / (t_scatter * 1e-3) / 1e9
         # The STRICT count: SURVEY.md 8(d) words the third term as the F rows "of Gaussians that RECEIVE WEIGHT in this
@@ -379,7 +406,9 @@ def main():
         # PMC counters cannot be collected from inside this process: `traffic` is the HBM byte count per launch of the
         # SAME kernel and workload from the committed rocprofv3 --pmc passes (tools/profile_round.sh, separate runs)
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-        scatter_kernel = ("k_blend<kFusedEnc> (encoder + blend + scatter in one kernel, no encoded map, no weight store)"
+        scatter_kernel = ("k_token_apply (token space: per-record token-quadrant weight sums from k_blend<kToken>, one plain "
+                          "read-modify-write per F row, no atomics)" if token_grid is not None else
+                          "k_blend<kFusedEnc> (encoder + blend + scatter in one kernel, no encoded map, no weight store)"
                           if fused_small and encoder is not None and args.encoder == "blend" else
                           ("k_blend_scatter_quarter" if gsbp_amd.Engine.fused_max_dim(W, H) > gsbp_amd.Engine.FUSED_MAX_DIM
                            else "k_blend<kFused>") + " (blend + scatter in one kernel, no weight store)" if fused_small else
@@ -394,6 +423,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg.name}: {N} Gaussians, {W}x{H} views, D={D_in}"
                                    + (f"->{D} (encoder)" if encoder is not None else "")
+                                   + (f", {cfg.lowres[0]}x{cfg.lowres[1]} network map upsampled ({up}) inside the kernels, "
+                                      f"reduction={cfg.reduction}" if cfg.lowres else "")
                                    + (f", the same {args.total_views} views sharded r, r+R, .. over {world} GPU(s)" if strong
                                       else f", {args.steps} views/GPU, view-sharded over {world} GPU(s)")
                                    + ", one reduce-scatter of F + all-reduce of d",
@@ -415,6 +446,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": b_scatter, "launch_ms": t_scatter,
+                         "survey_formula_bytes": b_survey,
                          "n_touched_per_view": n_touched,
                          "algorithmic_bytes_strict": b_strict,
                          "frac_strict": (b_strict / (t_scatter * 1e-3) / 1e9 / HBM_PEAK_GBS) if b_strict else None,
@@ -479,7 +511,8 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def check_results(args, gsbp_amd, eng, views, g, pool, encoder, F_rows, d_sum, row0, use_dist, dist, dev):
+def check_results(args, gsbp_amd, eng, views, g, pool, encoder, F_rows, d_sum, row0, use_dist, dist, dev, cfg, syn, sf=1.0,
+                  sd=1.0):
     """Outside the timed region: is what the timed region left in F and d right?
 
     A second pass over the SAME timed views on ONE stream through a different kernel path -- D = 1 probe maps
@@ -493,7 +526,10 @@ def check_results(args, gsbp_amd, eng, views, g, pool, encoder, F_rows, d_sum, r
     gen = torch.Generator(device=dev).manual_seed(4242)
     u = torch.randn(D, generator=gen, device=dev)
     u /= u.norm()
-    probes = [((p if encoder is None else p @ encoder) @ u)[..., None].contiguous() for p in pool]
+    # (a low-resolution network map: the probe is upsampled with the reference's OWN op, F.interpolate -- upsampling is linear, so
+    # upsample(map) . u == upsample(map . u) -- and scattered at full resolution: the check does not share the product's
+    # upsampling kernels or its token-space path)
+    probes = [syn.upsample_map(cfg, ((p if encoder is None else p @ encoder) @ u)[..., None]).contiguous() for p in pool]
     # The check side is summed in float64: each view's G_v and d_v are formed in fp32 by the kernel (one view: ~1e-7) and added to
     # float64 totals, so that only the PRODUCT's fp32 accumulation error is left in the comparison (with both sides fp32
     # sums in different orders the bound had to absorb twice the rounding noise).
@@ -511,7 +547,7 @@ def check_results(args, gsbp_amd, eng, views, g, pool, encoder, F_rows, d_sum, r
         alphas = eng.blend_weights(views[i], want_alphas=True)
         Gv.zero_()
         dv.zero_()
-        eng.scatter(views[i], probes[i % args.pool], Gv, dv)
+        eng.scatter(views[i], probes[i % args.pool], Gv, dv, sf, sd)
         G += Gv
         dG += dv
         n_touched += (dv > 0).sum()  # Gaussians that receive weight in THIS view (the strict roofline count)
@@ -558,7 +594,9 @@ def cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder,
     h = [t.cpu().numpy() for t in (means, quats, scales, opac)]
     Fc = np.zeros((cfg.n_gaussians, D), np.float32)
     dc = np.zeros(cfg.n_gaussians, np.float32)
-    feats = [(p if encoder is None else p @ encoder).cpu().numpy() for p in pool[:n_views]]
+    # (low-resolution network maps: the reference back-projects the MATERIALISED upsampled map; two of them, 6.9 GB each for dino)
+    feats = [syn.upsample_map(cfg, p if encoder is None else p @ encoder).contiguous().cpu().numpy()
+             for p in pool[:(2 if cfg.lowres else n_views)]]
     orc.lib()
     pairs, t = 0, 0.0
     for v in range(n_views):

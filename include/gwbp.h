@@ -99,10 +99,11 @@ typedef struct gwbp_stats {
     uint32_t n_headers;   /* (Gaussian, tile) pairs with at least one contributing pixel */
     uint32_t pool_used;   /* weight-pool entries a uniform shard capacity would need: kShards x fullest shard */
     uint32_t overflow;    /* bit0: isect_cap exceeded, bit1: pair_cap exceeded -> results of this view invalid;
+                           * bit3: gwbp_blend_tokens met a tile that spans more than 2 x 2 tokens (precondition violated) -> invalid;
                            * bit2: gwbp_scatter / gwbp_accumulate_d asked for the 256-channel kernel on a view that was
                            * blended WITH GWBP_FLAG_NARROW_SCATTER (no half-tile lists / weight sums): that call left
                            * F and d untouched -- scatter again with the flag set */
-    uint32_t reserved;    /* what the last blend of this view left: 0 = weight store, 1 = store + half-tile lists, 2 = nothing (gwbp_blend_scatter) */
+    uint32_t reserved;    /* what the last blend of this view left: 0 = weight store, 1 = store + half-tile lists, 2 = nothing (gwbp_blend_scatter), 3 = token-quadrant weight sums (gwbp_blend_tokens) */
 } gwbp_stats;
 
 /* Library / build identification ("gfx950;<git-less build tag>"). */
@@ -159,6 +160,28 @@ GWBP_API int gwbp_blend_scatter(const gwbp_caps *caps, void *workspace, size_t w
 GWBP_API int gwbp_blend_scatter_encoded(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
                                const float *feats, int64_t fs_y, int64_t fs_x, int32_t K, const float *encoder, int32_t n_out,
                                float scale_f, float scale_d, float *F, float *d, float *alphas, void *stream);
+
+/* The dino variant in TOKEN space (backproject.py:242-289: 64 x 64 x 1024 patch tokens, F.interpolate(mode="nearest") to the
+ * view's size, then the back-projection).  All pixels of a token carry the same vector, so F_v[g,:] = sum_t omega_{g,t} tok[t,:]
+ * with omega_{g,t} = sum_{p in t} w_g(p).  gwbp_blend_tokens is gwbp_blend_weights whose product is those sums instead of a
+ * weight store: per contributing (Gaussian, tile) record the weight sums of the tile's (at most) 2 x 2 tokens, filed at the
+ * record's emit position so that the sums of one Gaussian lie back to back.  gwbp_scatter_tokens then adds
+ *     F[g,:] += scale_f * sum_t omega_{g,t} tokens[t,:],   d[g] += scale_d * sum_t omega_{g,t}
+ * with ONE plain read-modify-write of every row that receives weight: no atomics, no weight store, deterministic.
+ * PRECONDITION: ymap[view.height] / xmap[view.width] (int32 device arrays, PyTorch's nearest rule, non-decreasing) send the 16
+ * pixels of any tile row / column to at most TWO consecutive tokens, i.e. a token is at least a tile wide and high
+ * (16 * lr_w <= width and 16 * lr_h <= height suffice); a tile that violates it sets gwbp_stats.overflow bit 3 and the view's
+ * result is invalid -- use gwbp_scatter_upsampled for finer maps.  The weights are gwbp_blend_weights' bit for bit (the alpha map
+ * too); F and d equal gwbp_scatter_upsampled's up to summation order.  After gwbp_blend_tokens the workspace holds NO weight
+ * store (gwbp_stats.reserved reads 3): gwbp_scatter / gwbp_render of that view add nothing.
+ * gwbp_scatter_tokens: tokens[row * ts_y + col * ts_x + c], channel-contiguous 16-B aligned rows, D % 256 == 0; d may be NULL;
+ * needs gwbp_project + gwbp_bin_sort + gwbp_blend_tokens of the same view in this workspace (anything else sets overflow bit 2
+ * and leaves F and d untouched). */
+GWBP_API int gwbp_blend_tokens(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                               const int32_t *ymap, const int32_t *xmap, float *alphas, void *stream);
+GWBP_API int gwbp_scatter_tokens(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,
+                                 const float *tokens, int64_t ts_y, int64_t ts_x, int32_t D, const int32_t *ymap,
+                                 const int32_t *xmap, float scale_f, float scale_d, float *F, float *d, void *stream);
 
 /* d[g] += scale_d * sum_p w_g(p) alone, from the per-record weight sums gwbp_blend_weights left in the workspace
  * (needs a blend WITHOUT GWBP_FLAG_NARROW_SCATTER).  A caller that overlaps the front stage of view v+1 with the

@@ -258,10 +258,13 @@ def test_c5_full_size_encoder_path_against_oracle(dev, orc):
     assert np.abs(out.cpu().numpy() - orc.finalize(Fr, dr)).max() <= 1e-4
 
 
-def test_dino_width_1024_nearest_64x64_mean_reduction(dev, orc):
+@pytest.mark.parametrize("token_space", [True, False], ids=["token_space", "pixel_slabs"])
+def test_dino_width_1024_nearest_64x64_mean_reduction(dev, orc, token_space):
     """create_feature_field_dino at its real width (backproject.py:201-210,242-289): D = 1024, a 64x64 patch-token map
-    nearest-upsampled to the view inside the scatter kernel, .mean() reductions; C2 geometry (1M Gaussians), two views,
-    against the oracle fed the materialised F.interpolate(mode="nearest") map, on a 64 k-row subset."""
+    nearest-upsampled to the view, .mean() reductions; C2 geometry (1M Gaussians), two views, against the oracle fed the
+    materialised F.interpolate(mode="nearest") map, on a 64 k-row subset.  Both product paths: TOKEN space (round 6, the default
+    for this shape: per-record token-quadrant weight sums + one plain read-modify-write per F row, csrc/token.hip) and the
+    pixel-slab kernels with index maps (gwbp_scatter_upsampled)."""
     cfg = syn.CONFIGS["C2"]
     N, D, V = cfg.n_gaussians, 1024, 2
     g_cpu = syn.activate(syn.make_scene(cfg))
@@ -272,7 +275,7 @@ def test_dino_width_1024_nearest_64x64_mean_reduction(dev, orc):
     low_dev = [t.to(dev) for t in low]
     out, F, d, st = gsbp_amd.create_feature_field(*g, vms.to(dev), K.to(dev), cfg.width, cfg.height,
                                                   lambda v: low_dev[v], D, reduction="mean", upsample="nearest",
-                                                  return_partials=True)
+                                                  return_partials=True, token_space=token_space)
     assert st["overflow"] == 0
     sel = np.arange(0, N, N // 65536)[:65536]
     rows = np.full(N, -1, np.int32)

@@ -688,6 +688,111 @@ def test_scatter_nearest_upsampled_lowres_map(orc, dev, D):
         eng.scatter(view, low.to(dev), F1, d1)  # a low-resolution map without upsample= is a shape error
 
 
+@pytest.mark.parametrize("D", [256, 512, 768, 1024])
+def test_token_space_scatter_against_oracle(orc, dev, D):
+    """Round 6: the dino variant in TOKEN space (backproject.py:242-289).  An 8 x 12 map at 200 x 136 has texels of 17 x 16.7
+    pixels -- at least a tile -- so every tile sees at most 2 x 2 of them: Engine.blend_tokens leaves per-record token-quadrant
+    weight sums, Engine.scatter_tokens applies them with one plain read-modify-write per F row (1, 2, 3 and 4 channel chunks:
+    768 takes the chunk map that is not XCD-aligned).  Against the oracle fed the materialised F.interpolate(mode="nearest") map,
+    against the pixel-slab path, alpha map bit for bit with blend_weights, and -- no atomics -- bit-identical on a rerun."""
+    cfg, sc = scene_np("T1")
+    d, h = to_dev(sc, dev), npy(sc)
+    lh, lw = 8, 12
+    assert gsbp_amd.Engine.token_geometry_ok(lh, lw, cfg.height, cfg.width)
+    low = torch.randn(lh, lw, D, generator=torch.Generator().manual_seed(5))
+    up = torch.nn.functional.interpolate(low.permute(2, 0, 1)[None], size=(cfg.height, cfg.width), mode="nearest")[0]
+    up = np.ascontiguousarray(up.permute(1, 2, 0).numpy())
+    eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, tight_binning=True)
+    view, _, _ = _front(eng, d, cfg, 0, want=False)
+    a_ref = eng.blend_weights(view, want_alphas=True)
+    F0 = torch.zeros(cfg.n_gaussians, D, device=dev)
+    d0 = torch.zeros(cfg.n_gaussians, device=dev)
+    eng.scatter(view, low.to(dev), F0, d0, upsample="nearest")
+    st0 = eng.stats()
+    res = []
+    for _ in range(2):
+        a_tok = eng.blend_tokens(view, lh, lw, want_alphas=True)
+        F1 = torch.full((cfg.n_gaussians, D), 0.25, device=dev)  # accumulates INTO F and d
+        d1 = torch.full((cfg.n_gaussians,), 0.5, device=dev)
+        eng.scatter_tokens(view, low.to(dev), F1, d1, 2.0, 3.0)
+        res.append((F1, d1))
+    st1 = eng.stats()
+    assert st1["overflow"] == 0 and st1["n_pairs"] == st0["n_pairs"] and st1["n_headers"] == st0["n_headers"]
+    assert st1["blend_kind"] == 3
+    assert torch.equal(a_tok, a_ref)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])  # deterministic: no atomics
+    Fr = np.zeros((cfg.n_gaussians, D), np.float64)
+    dr = np.zeros(cfg.n_gaussians, np.float64)
+    orc.backproject_view(h["means"], h["quats"], h["scales"], h["opac"], h["vms"][0], h["K"], cfg.width, cfg.height, up, Fr, dr)
+    F1n, d1n = (res[0][0].cpu().numpy() - 0.25) / 2.0, (res[0][1].cpu().numpy() - 0.5) / 3.0
+    touched = dr > 0
+    assert rel_row_err(F1n, Fr) <= 1e-4
+    assert rel_row_err(d1n[:, None], dr[:, None]) <= 1e-4
+    assert np.array_equal(res[0][1].cpu().numpy() != 0.5, touched)  # exactly the Gaussians that receive weight are written
+    assert rel_row_err(F0.cpu().numpy(), Fr) <= 1e-4
+    with pytest.raises(gsbp_amd.GwbpError):
+        eng.scatter(view, low.to(dev), F0, d0, upsample="nearest")  # no weight store behind blend_tokens
+    with pytest.raises(gsbp_amd.GwbpError):
+        eng.blend_tokens(view, 13, 17)  # texels narrower than a tile
+
+
+def test_token_space_precondition_is_enforced_on_the_device(dev):
+    """The C ABI's own guard: index maps that send a tile to more than 2 x 2 texels raise gwbp_stats.overflow bit 3 (the Python
+    host never calls gwbp_blend_tokens with such maps; a foreign caller of the C ABI might)."""
+    import ctypes as C
+    from gsbp_amd._lib import ptr
+    cfg, sc = scene_np("T1")
+    d = to_dev(sc, dev)
+    eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev)
+    view, _, _ = _front(eng, d, cfg, 0, want=False)
+    ymap, xmap = eng.nearest_maps(13, 17, cfg.height, cfg.width)  # 10.5 x 11.8 pixel texels
+    eng._call("gwbp_blend_tokens", *eng._args(), C.byref(view), ptr(ymap), ptr(xmap), None, eng._stream())
+    assert eng.stats()["overflow"] & 8
+
+
+def test_token_space_non_finite_token_reaches_exactly_its_gaussians(orc, dev):
+    """A NaN token (backproject.py:239-241 can produce one) must reach exactly the Gaussians that have weight inside it."""
+    cfg, sc = scene_np("T1")
+    d, h = to_dev(sc, dev), npy(sc)
+    lh, lw, D = 8, 12, 256
+    low = torch.randn(lh, lw, D, generator=torch.Generator().manual_seed(6))
+    low[3, 5, 17] = float("nan")
+    low[6, 2, :] = float("inf")
+    up = torch.nn.functional.interpolate(low.permute(2, 0, 1)[None], size=(cfg.height, cfg.width), mode="nearest")[0]
+    up = np.ascontiguousarray(up.permute(1, 2, 0).numpy())
+    eng = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, tight_binning=True)
+    view, _, _ = _front(eng, d, cfg, 0, want=False)
+    eng.blend_tokens(view, lh, lw)
+    F1 = torch.zeros(cfg.n_gaussians, D, device=dev)
+    d1 = torch.zeros(cfg.n_gaussians, device=dev)
+    eng.scatter_tokens(view, low.to(dev), F1, d1)
+    Fr = np.zeros((cfg.n_gaussians, D), np.float64)
+    dr = np.zeros(cfg.n_gaussians, np.float64)
+    orc.backproject_view(h["means"], h["quats"], h["scales"], h["opac"], h["vms"][0], h["K"], cfg.width, cfg.height, up, Fr, dr)
+    bad, bad_ref = ~np.isfinite(F1.cpu().numpy()).all(1), ~np.isfinite(Fr).all(1)
+    assert bad_ref.sum() > 0 and np.array_equal(bad, bad_ref), (int(bad.sum()), int(bad_ref.sum()))
+    assert rel_row_err(F1.cpu().numpy()[~bad], Fr[~bad]) <= 1e-4
+
+
+def test_create_feature_field_token_space_equals_pixel_slabs(dev):
+    """The driver takes the token path by itself for a nearest-upsampled map whose texels cover a tile (pipelined and serial),
+    and both equal the pixel-slab kernels."""
+    cfg, sc = scene_np("T1", n_views=5)
+    d = to_dev(sc, dev)
+    vms = syn.make_cameras(cfg, n_views=5).to(dev)
+    D, lh, lw = 512, 8, 12
+    lows = [torch.randn(lh, lw, D, generator=torch.Generator().manual_seed(30 + v)).to(dev) for v in range(5)]
+    args = (d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"], cfg.width, cfg.height)
+    kw = dict(feature_fn=lambda v: lows[v], dim=D, reduction="mean", upsample="nearest", return_partials=True)
+    ref = gsbp_amd.create_feature_field(*args, **kw, token_space=False)
+    for pipeline in (True, False):
+        got = gsbp_amd.create_feature_field(*args, **kw, pipeline=pipeline)
+        assert got[3]["overflow"] == 0 and got[3]["n_pairs"] == ref[3]["n_pairs"]
+        assert rel_row_err(got[1].cpu().numpy(), ref[1].cpu().numpy()) <= 2e-5
+        assert np.abs((got[2] - ref[2]).cpu().numpy()).max() <= 1e-5 * float(ref[2].max())
+        assert rel_row_err(got[0].cpu().numpy(), ref[0].cpu().numpy()) <= 2e-5
+
+
 def test_create_feature_field_upsample_matches_materialised(dev):
     cfg, sc = scene_np("T1")
     d = to_dev(sc, dev)
