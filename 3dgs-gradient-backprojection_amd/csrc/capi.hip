@@ -115,6 +115,7 @@ int make_layout(const gwbp_caps *c, Layout *L)
     };
     L->counters = take(sizeof(Counters));
     L->shards = take((size_t)(kShards + kQueues) * 64);
+    L->sweep = take((size_t)kSweepWords * sizeof(u32)); // (inside the range gwbp_project's memset clears: counters .. g2d)
     L->g2d = take((size_t)L->n * sizeof(G2D));
     L->rect = take((size_t)L->n * sizeof(uint2));
     L->touched = take((size_t)L->n * sizeof(u32));
@@ -127,7 +128,8 @@ int make_layout(const gwbp_caps *c, Layout *L)
     L->keys[1] = take((size_t)L->isect_cap * sizeof(u32));
     L->vals[0] = take((size_t)L->isect_cap * sizeof(u32));
     L->vals[1] = take((size_t)L->isect_cap * sizeof(u32));
-    L->hist = take((size_t)256 * L->n_sort_blocks * sizeof(u32));
+    // two look-back status buffers [block][256 digits] of 8-B words, used alternately by the passes of a sort level
+    L->hist = take((size_t)2 * 256 * L->n_sort_blocks * sizeof(u64));
     L->digit_total = take(256 * sizeof(u32));
     L->tile_offsets = take((size_t)(L->max_tiles + 1) * sizeof(u32));
     L->tile_order = take((size_t)L->max_tiles * sizeof(u32));
@@ -156,6 +158,7 @@ int bind_workspace(const gwbp_caps *caps, void *ws, size_t bytes, Layout *L, Ws 
     char *b = static_cast<char *>(ws);
     W->counters = reinterpret_cast<Counters *>(b + L->counters);
     W->shards = reinterpret_cast<u32 *>(b + L->shards);
+    W->sweep = reinterpret_cast<u32 *>(b + L->sweep);
     W->g2d = reinterpret_cast<G2D *>(b + L->g2d);
     W->rect = reinterpret_cast<uint2 *>(b + L->rect);
     W->touched = reinterpret_cast<u32 *>(b + L->touched);

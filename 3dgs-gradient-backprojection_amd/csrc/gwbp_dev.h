@@ -28,6 +28,11 @@ constexpr unsigned kPadPix = 640;    // "pixel" of a padding entry {0, kPadPix}:
                                      // other consumer masks the padding by the quarters' counts
 constexpr int kSortItems = 4096;     // keys per sort block (256 threads x 16)
 constexpr int kScanBlock = 256;      // Gaussians per project/emit block
+constexpr int kMaxPasses = 4;        // 8-bit passes per sort level (32-bit keys)
+// the sort's small tables, cleared with the counters by gwbp_project's memset: digit totals [2 levels][kMaxPasses][256] (one
+// k_hist_all per level fills a level's tables from one read of the keys), then one block ticket per (level, pass)
+constexpr int kSweepTickets = 2 * kMaxPasses * 256;
+constexpr int kSweepWords = kSweepTickets + 2 * kMaxPasses;
 
 // ---- device-resident tables -------------------------------------------------------------------------------
 // Projected Gaussian, 32 B, read by the blend kernel with two 16-B loads.
@@ -86,7 +91,7 @@ static_assert(sizeof(Counters) == sizeof(gwbp_stats), "Counters must mirror gwbp
 
 struct Layout {
     size_t total;
-    size_t counters, shards, g2d, rect, touched, blocksums, dkeys[2], dvals[2], keys[2], vals[2], hist, digit_total, tile_offsets, tile_order, hdr_count,
+    size_t counters, shards, sweep, g2d, rect, touched, blocksums, dkeys[2], dvals[2], keys[2], vals[2], hist, digit_total, tile_offsets, tile_order, hdr_count,
         headers, carry, wpool;
     int64_t n, isect_cap, pair_cap;
     int max_tiles, n_scan_blocks, n_sort_blocks, scatter_wgs, flags;
@@ -95,6 +100,7 @@ struct Layout {
 struct Ws {
     Counters *counters;
     u32 *shards; // kShards head words, 16 u32 apart
+    u32 *sweep;  // kSweepWords: digit totals of every sort pass + block tickets (zero between gwbp_bin_sort calls)
     G2D *g2d;
     uint2 *rect; // x = xmin | xmax<<16, y = ymin | ymax<<16
     u32 *touched;

@@ -10,10 +10,15 @@
 // The number of intersections lives in device memory (Counters::n_isect), so the level-2 kernels are launched for
 // the caller's capacity and idle blocks exit at once: no host read-back between projection and blend.
 //
-// Per 8-bit pass: (1) k_hist   - per-block digit histogram, hist[digit][block]
+// Round 6 ("front diet"): per LEVEL one k_hist_all that reads the keys ONCE and produces the digit totals of every pass, then
+// ONE kernel per 8-bit pass, k_onesweep: wave-striped stable ranking (ballot "match" per digit, per-wave LDS counters) as
+// before, but a block's base inside each digit comes from a DECOUPLED LOOK-BACK over the blocks in front of it (status words
+// {flag, count} per (block, digit); blocks take their index from a ticket, so a block only ever waits for blocks that have
+// started) instead of from a per-pass histogram kernel + a scan kernel: 18 launches and three reads of the keys per pass
+// became 8 launches and (1/passes + 2) reads.  Rounds 1-5 (kept behind -DGWBP_SORT_3K for same-box A/B builds):
+//                 (1) k_hist   - per-block digit histogram, hist[digit][block]
 //                 (2) k_scan   - one workgroup per digit: exclusive scan over blocks + digit total
-//                 (3) k_radix_scatter - wave-striped stable ranking (ballot "match" per digit, per-wave LDS
-//                                counters), keys/values kept in registers between ranking and scatter.
+//                 (3) k_radix_scatter - the ranking + scatter described above, bases from (1) and (2).
 #include "gwbp_dev.h"
 
 namespace gwbp {
@@ -170,6 +175,173 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u32 *__res
             const u32 c = s_cnt[w][d];
             s_cnt[w][d] = run;
             run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kItemsPerThread; ++it) {
+        const u32 idx = seg + it * 64 + lane;
+        if (idx < n) {
+            const u32 key = keys_in[idx];
+            const u32 pos = s_cnt[wave][(key >> shift) & 0xFFu] + r_rank[it];
+            keys_out[pos] = key;
+            vals_out[pos] = vals_in[idx];
+        }
+    }
+}
+
+
+// ---- round 6: one histogram kernel per level + one look-back kernel per pass ---------------------------------------------------
+constexpr u64 kFlagAggregate = 1ull << 32, kFlagInclusive = 2ull << 32; // status word = flag << 32 | count (counts reach 2^32 - 4096)
+
+// Digit totals of ALL passes of a level from one read of the keys: per-block LDS histograms (passes x 256 bins), non-zero bins
+// added to the level's tables with global atomics (the tables live in the region gwbp_project's memset clears, and the last
+// kernel of gwbp_bin_sort clears them again).  Each active block also zeroes its row of status buffer 0 for the first pass.
+__global__ __launch_bounds__(kSortThreads) void k_hist_all(const u32 *__restrict__ keys, const u32 *__restrict__ n_dev, u32 n_host,
+                                                           int passes, u32 *__restrict__ totals, u64 *__restrict__ status0, int prio)
+{
+    front_priority(prio);
+    const u32 n = n_dev ? *n_dev : n_host;
+    const u32 base = blockIdx.x * (u32)kSortItems;
+    if (base >= n)
+        return; // launched for the capacity: blocks beyond the data leave at once
+    __shared__ u32 s_h[kMaxPasses][256];
+#pragma unroll
+    for (int p = 0; p < kMaxPasses; ++p)
+        s_h[p][threadIdx.x] = 0;
+    status0[(size_t)blockIdx.x * 256 + threadIdx.x] = 0ull;
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < kItemsPerThread; ++it) {
+        const u32 idx = base + it * kSortThreads + threadIdx.x;
+        if (idx < n) {
+            const u32 key = keys[idx];
+            for (int p = 0; p < passes; ++p)
+                atomicAdd(&s_h[p][(key >> (8 * p)) & 0xFFu], 1u);
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < passes; ++p) {
+        const u32 c = s_h[p][threadIdx.x];
+        if (c)
+            atomicAdd(&totals[p * 256 + threadIdx.x], c);
+    }
+}
+
+// One 8-bit pass.  totals = this pass's 256 digit totals; status = this pass's look-back words [block][digit] (zero on entry),
+// status_next = the other buffer, whose row this block zeroes for the next pass; ticket = this pass's block counter.
+__global__ __launch_bounds__(kSortThreads) void k_onesweep(const u32 *__restrict__ keys_in, const u32 *__restrict__ vals_in,
+                                                           u32 *__restrict__ keys_out, u32 *__restrict__ vals_out,
+                                                           const u32 *__restrict__ n_dev, u32 n_host, int shift,
+                                                           const u32 *__restrict__ totals, u64 *__restrict__ status,
+                                                           u64 *__restrict__ status_next, u32 *__restrict__ ticket, int prio)
+{
+    front_priority(prio);
+    const u32 n = n_dev ? *n_dev : n_host;
+    if (blockIdx.x * (u32)kSortItems >= n)
+        return; // exactly ceil(n / kSortItems) blocks stay and take tickets 0 .. that - 1
+    __shared__ u32 s_cnt[kWaves][256]; // per-wave running digit counters, then per-wave bases
+    __shared__ u32 s_start[256];       // global start of each digit (exclusive scan of the digit totals)
+    __shared__ u32 s_tile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        s_tile = atomicAdd(ticket, 1u); // the block's index = its place in the START order: everything in front of it runs or is done
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w)
+        s_cnt[w][threadIdx.x] = 0;
+    { // exclusive scan of the 256 digit totals
+        const u32 v = totals[threadIdx.x];
+        u32 incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(incl, o, 64);
+            if (lane >= o)
+                incl += t;
+        }
+        __shared__ u32 s_w[kWaves];
+        if (lane == 63)
+            s_w[wave] = incl;
+        __syncthreads();
+        u32 woff = 0;
+        for (int w = 0; w < wave; ++w)
+            woff += s_w[w];
+        s_start[threadIdx.x] = woff + incl - v;
+    }
+    __syncthreads();
+    const u32 tile = s_tile;
+    const u32 base = tile * (u32)kSortItems;
+    status_next[(size_t)tile * 256 + threadIdx.x] = 0ull;
+
+    // (ranking exactly as in k_radix_scatter: only the ranks survive the barriers, keys and values are re-read for the scatter)
+    u32 r_rank[kItemsPerThread];
+    const u32 seg = base + wave * (u32)kWaveItems;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int it = 0; it < kItemsPerThread; ++it) {
+        const u32 idx = seg + it * 64 + lane;
+        const bool valid = idx < n;
+        const u32 key = valid ? keys_in[idx] : ~0u;
+        const u32 dg = (u32)(key >> shift) & 0xFFu;
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (dg >> b) & 1u;
+            const u64 m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        u32 old = 0;
+        const int leader = valid ? (__ffsll((long long)peers) - 1) : 0;
+        if (valid && lane == leader) {
+            old = s_cnt[wave][dg];
+            s_cnt[wave][dg] = old + (u32)__popcll(peers);
+        }
+        old = __shfl(old, leader, 64);
+        r_rank[it] = old + (u32)__popcll(peers & lt);
+    }
+    __syncthreads();
+    { // thread = digit: publish this block's count, look back for the blocks in front, turn per-wave counts into global bases
+        const u32 d = threadIdx.x;
+        u32 c[kWaves], mine = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            c[w] = s_cnt[w][d];
+            mine += c[w];
+        }
+        u64 *row = status + d;
+        __hip_atomic_store(row + (size_t)tile * 256, (tile == 0 ? kFlagInclusive : kFlagAggregate) | (u64)mine, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        u32 excl = 0;
+        if (tile != 0) {
+            // four predecessors' words in flight at a time; an empty word (its block has not ranked yet) is polled again
+            long long j = (long long)tile - 1;
+            bool done = false;
+            while (!done) {
+                u64 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    v[u] = (j - u >= 0) ? __hip_atomic_load(row + (size_t)(j - u) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : kFlagInclusive;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (done)
+                        break;
+                    while ((v[u] >> 32) == 0ull) {
+                        __builtin_amdgcn_s_sleep(1);
+                        v[u] = __hip_atomic_load(row + (size_t)(j - u) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    excl += (u32)v[u];
+                    done = (v[u] >> 32) == 2ull;
+                }
+                j -= 4;
+            }
+            __hip_atomic_store(row + (size_t)tile * 256, kFlagInclusive | (u64)(excl + mine), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        u32 run = s_start[d] + excl;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            s_cnt[w][d] = run;
+            run += c[w];
         }
     }
     __syncthreads();
@@ -402,9 +574,13 @@ __global__ void k_export_sorted(const u32 *__restrict__ keys, const u32 *__restr
 // k_scan_blocksums).
 constexpr int kOrderThreads = 256;
 __global__ __launch_bounds__(kOrderThreads) void k_tile_order(const u32 *__restrict__ tile_offsets, int n_tiles,
-                                                              u32 *__restrict__ order, int prio)
+                                                              u32 *__restrict__ order, u32 *__restrict__ sweep, int prio)
 {
     front_priority(prio);
+    // the last kernel of gwbp_bin_sort leaves the sort's digit tables and tickets zero for the next call on this workspace
+    // (gwbp_project's memset clears them as well: a view normally starts there)
+    for (int i = threadIdx.x; i < kSweepWords; i += kOrderThreads)
+        sweep[i] = 0u;
     __shared__ u32 s_cnt[1024];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -455,9 +631,23 @@ __global__ void k_copy_u32(const u32 *__restrict__ src, int32_t *__restrict__ ds
         dst[i] = (int32_t)src[i];
 }
 
-static void radix_passes(const Ws &W, u32 *const keys[2], u32 *const vals[2], const u32 *n_dev, u32 n_host, int nblk,
-                         int passes, int prio, hipStream_t s)
+// `level` 0 = the depth sort of the Gaussians (tables 0..3, tickets 0..3), 1 = the tile sort of the intersections (4..7)
+static void radix_passes(const Layout &L, const Ws &W, u32 *const keys[2], u32 *const vals[2], const u32 *n_dev, u32 n_host,
+                         int nblk, int passes, int prio, int level, hipStream_t s)
 {
+#ifndef GWBP_SORT_3K
+    u64 *status[2] = {reinterpret_cast<u64 *>(W.hist), reinterpret_cast<u64 *>(W.hist) + (size_t)L.n_sort_blocks * 256};
+    u32 *totals = W.sweep + level * kMaxPasses * 256;
+    u32 *tickets = W.sweep + kSweepTickets + level * kMaxPasses;
+    hipLaunchKernelGGL(k_hist_all, dim3(nblk), dim3(kSortThreads), 0, s, keys[0], n_dev, n_host, passes, totals, status[0], prio);
+    for (int p = 0; p < passes; ++p) {
+        const int in = p & 1, out = in ^ 1;
+        hipLaunchKernelGGL(k_onesweep, dim3(nblk), dim3(kSortThreads), 0, s, keys[in], vals[in], keys[out], vals[out], n_dev, n_host,
+                           p * 8, totals + p * 256, status[p & 1], status[(p + 1) & 1], tickets + p, prio);
+    }
+    return;
+#endif
+    (void)level;
     for (int p = 0; p < passes; ++p) {
         const int in = p & 1, out = in ^ 1;
         hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(kSortThreads), 0, s, keys[in], n_dev, n_host, p * 8, nblk, W.hist, prio);
@@ -487,7 +677,7 @@ int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *ise
             if (rc1 || (rc1 = launch_emit_scanned(L, W, V, W.dvals[0], s)))
                 return rc1;
         } else {
-            radix_passes(W, W.dkeys, W.dvals, nullptr, (u32)L.n, nblk1, 4, prio, s);
+            radix_passes(L, W, W.dkeys, W.dvals, nullptr, (u32)L.n, nblk1, 4, prio, 0, s);
             // emit intersections front to back
             const int rc = launch_emit(L, W, V, W.dvals[0], s);
             if (rc)
@@ -497,12 +687,12 @@ int launch_bin_sort(const Layout &L, const Ws &W, const ViewDev &V, int64_t *ise
     // level 2: intersections by tile id
     const int passes = sort_passes(n_tiles);
     const int nblk2 = (int)((L.isect_cap + kSortItems - 1) / kSortItems);
-    radix_passes(W, W.keys, W.vals, &W.counters->n_isect, 0u, nblk2, passes, prio, s);
+    radix_passes(L, W, W.keys, W.vals, &W.counters->n_isect, 0u, nblk2, passes, prio, 1, s);
     const int fin = passes & 1;
     const int ob = (int)((L.isect_cap + 255) / 256);
     hipLaunchKernelGGL(k_tile_offsets, dim3(ob > 0 ? (ob < 4096 ? ob : 4096) : 1), dim3(256), 0, s, W.keys[fin], W.counters, n_tiles,
                        W.tile_offsets, prio);
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kOrderThreads), 0, s, W.tile_offsets, n_tiles, W.tile_order, prio);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kOrderThreads), 0, s, W.tile_offsets, n_tiles, W.tile_order, W.sweep, prio);
     if (isect_ids || flatten_ids)
         hipLaunchKernelGGL(k_export_sorted, dim3(1024), dim3(256), 0, s, W.keys[fin], W.vals[fin], W.g2d, W.counters,
                            L.isect_cap, isect_ids, flatten_ids);

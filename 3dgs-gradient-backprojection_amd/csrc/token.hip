@@ -15,9 +15,10 @@
 // HBM traffic per view: 8 B x D per Gaussian that receives weight (C2 geometry, D = 1024: 0.53 M rows -> 4.4 GB) + the 16-B sums
 // (0.06 GB); the token rows (about five 4-KB rows per touched Gaussian) come from L2 / Infinity Cache.
 //
-// XCD-aware work map: the channels are cut into 256-channel chunks and a workgroup's chunk is its XCD class (blockIdx % 8)
-// modulo the chunk count, so each XCD's 4 MB L2 keeps re-reading the SAME 256-channel slice of the token map (64 x 64 tokens x 1 KB
-// = 4 MB at D = 1024) while the F rows stream past it with non-temporal loads and stores.
+// Work map: one wave walks 16 consecutive Gaussians of the depth order (= the emit order: their sums are contiguous), one Gaussian at
+// a time over ALL its channels (up to four 256-channel chunks side by side), with the next Gaussian's sums requested a Gaussian
+// ahead.  (First version, measured at 2.17 ms per C2-geometry view at D = 1024: one (Gaussian, 256-channel chunk) per wave
+// iteration with the chunk tied to the XCD so that each L2 kept one 4 MB slice of the token map -- 3.4 M short dependent chains.)
 #include "gwbp_dev.h"
 
 namespace gwbp {
@@ -47,12 +48,16 @@ struct TokenApplyArgs {
     const int32_t *ymap, *xmap;
     const float *tokens; // tokens[row * ts_y + col * ts_x + c]
     int64_t ts_y, ts_x;
-    int D, n_chunks, W, H;
+    int D, W, H;
     float scale_f, scale_d;
     float *F, *d;
     Counters *ctr;
 };
 
+// One wave = one Gaussian at a time, ALL its channels: NC chunks of 256 channels side by side (NC x float4 per lane; D = 1024:
+// NC = 4, one pass), so the Gaussian's weight sums are read and decoded once and every token row read / F row read-modify-write
+// of the Gaussian is in flight together.  The sums of the NEXT Gaussian are requested before this one is worked on.
+template <int NC>
 __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A)
 {
     if (A.ctr->blend_kind != kBlendToken) { // the view in this workspace was not blended by gwbp_blend_tokens
@@ -61,17 +66,7 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
         return;
     }
     const int lane = (int)(threadIdx.x & 63u), wave = (int)uniform(threadIdx.x >> 6);
-    // chunk = XCD class modulo the chunk count when that divides 8 (1, 2, 4, 8 chunks); any other count: plain interleave
-    u32 chunk, group;
-    if (8 % A.n_chunks == 0) {
-        const u32 xcd = blockIdx.x & 7u, per = 8u / (u32)A.n_chunks;
-        chunk = xcd % (u32)A.n_chunks;
-        group = (blockIdx.x >> 3) * per + xcd / (u32)A.n_chunks;
-    } else {
-        chunk = blockIdx.x % (u32)A.n_chunks;
-        group = blockIdx.x / (u32)A.n_chunks;
-    }
-    const int64_t i0 = (int64_t)group * kTokGroup + wave * kTokPerWave;
+    const int64_t i0 = (int64_t)blockIdx.x * kTokGroup + wave * kTokPerWave;
     if (i0 >= A.N)
         return;
     // lanes 0..15: the wave's Gaussians
@@ -85,78 +80,104 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
             m_rx = rc.x, m_ry = rc.y;
         }
     }
-    const u64 live = __ballot(m_cnt != 0u);
-    if (live == 0ull)
+    u64 rest = __ballot(m_cnt != 0u);
+    if (rest == 0ull)
         return;
     const int quad = lane & 3, sl = lane >> 2; // lane = (slot within a batch of 16, token quadrant qx | qy << 1)
-    const size_t coff = (size_t)chunk * kTokCh + (size_t)lane * 4;
-    for (u64 rest = live; rest != 0ull; rest &= rest - 1) {
+    const int n_pass = A.D / (kTokCh * NC);
+    auto first_batch = [&](int k) -> float { // the first 16 slots' sums of the wave's k-th Gaussian: 256 contiguous bytes
+        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k), es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
+        return (u32)sl < cnt ? A.omega[(size_t)(es + (u32)sl) * 4 + quad] : 0.f;
+    };
+    float om_next = first_batch(__ffsll((long long)rest) - 1);
+    while (rest != 0ull) {
         const int k = __ffsll((long long)rest) - 1;
+        rest &= rest - 1;
+        const float om_first = om_next;
+        if (rest != 0ull)
+            om_next = first_batch(__ffsll((long long)rest) - 1); // lands under this Gaussian's row traffic
         const u32 gid = (u32)__builtin_amdgcn_readlane((int)m_gid, k), cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k);
         const u32 es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
         const u32 rx = (u32)__builtin_amdgcn_readlane((int)m_rx, k), ry = (u32)__builtin_amdgcn_readlane((int)m_ry, k);
         const u32 x0 = rx & 0xFFFFu, rw = (rx >> 16) - x0, y0 = ry & 0xFFFFu;
-        float *frow = A.F + (size_t)gid * (size_t)A.D + coff;
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
-        float dsum = 0.f;
-        bool any = false; // wave-uniform: some sum of this Gaussian is non-zero
-        f4 fold = {0.f, 0.f, 0.f, 0.f};
-        for (u32 s0 = 0; s0 < cnt; s0 += 16u) {
-            const u32 slot = s0 + (u32)sl;
-            const float om = slot < cnt ? A.omega[(size_t)(es + slot) * 4 + quad] : 0.f; // 256 contiguous bytes per batch
-            const u64 nz = __ballot(om != 0.f);
-            if (nz == 0ull)
-                continue;
-            if (!any) { // first weight of this Gaussian: start the row's read now, it lands under the token reads
-                any = true;
-                fold = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(frow));
-            }
-            dsum += om;
-            // the token under this lane's (tile, quadrant): first token of the tile + (qx, qy); only dereferenced where om != 0,
-            // i.e. where the blend found a pixel of that token
-            const u32 ty = y0 + slot / rw, tx = x0 + slot % rw;
-            const int tc = A.xmap[min((int)(tx * kTile), A.W - 1)] + (quad & 1);
-            const int tr = A.ymap[min((int)(ty * kTile), A.H - 1)] + (quad >> 1);
-            const long long toff = (long long)tr * A.ts_y + (long long)tc * A.ts_x;
-            const int tlo = (int)(u32)toff, thi = (int)(toff >> 32);
-            u64 todo = nz;
-            while (todo != 0ull) { // four entries' rows in flight
-                f4 t[4];
-                float w[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    w[u] = 0.f;
-                    t[u] = f4{0.f, 0.f, 0.f, 0.f};
-                    if (todo != 0ull) { // wave-uniform
-                        const int l = __ffsll((long long)todo) - 1;
-                        todo &= todo - 1;
-                        w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(om), l));
-                        const long long o = ((long long)__builtin_amdgcn_readlane(thi, l) << 32) |
-                                            (long long)(u32)__builtin_amdgcn_readlane(tlo, l);
-                        t[u] = *reinterpret_cast<const f4 *>(A.tokens + o + (long long)coff);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (w[u] != 0.f) { // (wave-uniform; a skipped slot must not turn 0 x NaN into NaN)
-                        acc.x = __builtin_fmaf(w[u], t[u].x, acc.x);
-                        acc.y = __builtin_fmaf(w[u], t[u].y, acc.y);
-                        acc.z = __builtin_fmaf(w[u], t[u].z, acc.z);
-                        acc.w = __builtin_fmaf(w[u], t[u].w, acc.w);
-                    }
-            }
-        }
-        if (!any)
+        if (cnt <= 16u && __ballot(om_first != 0.f) == 0ull)
             continue; // visible, binned, but no pixel with weight: F and d keep their values (nothing is read or written)
-        fold.x = __builtin_fmaf(A.scale_f, acc.x, fold.x);
-        fold.y = __builtin_fmaf(A.scale_f, acc.y, fold.y);
-        fold.z = __builtin_fmaf(A.scale_f, acc.z, fold.z);
-        fold.w = __builtin_fmaf(A.scale_f, acc.w, fold.w);
-        __builtin_nontemporal_store(fold, reinterpret_cast<f4 *>(frow));
-        if (chunk == 0 && A.d) { // one wave per Gaussian owns d[gid] as well: plain read-modify-write
-            const float tot = wave_sum(dsum);
-            if (lane == 0)
-                A.d[gid] = __builtin_fmaf(A.scale_d, tot, A.d[gid]);
+        float dsum = 0.f;
+        for (int pass = 0; pass < n_pass; ++pass) {
+            float *frow = A.F + (size_t)gid * (size_t)A.D + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
+            const float *tbase = A.tokens + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
+            f4 acc[NC], fold[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                acc[c] = f4{0.f, 0.f, 0.f, 0.f};
+            bool any = false; // wave-uniform: some sum of this Gaussian is non-zero
+            for (u32 s0 = 0; s0 < cnt; s0 += 16u) {
+                const u32 slot = s0 + (u32)sl;
+                const float om = s0 == 0u ? om_first : (slot < cnt ? A.omega[(size_t)(es + slot) * 4 + quad] : 0.f);
+                const u64 nz = __ballot(om != 0.f);
+                if (nz == 0ull)
+                    continue;
+                if (!any) { // first weight of this Gaussian: start the row's read now, it lands under the token reads
+                    any = true;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        fold[c] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(frow + c * kTokCh));
+                }
+                if (pass == 0)
+                    dsum += om;
+                // the token under this lane's (tile, quadrant): first token of the tile + (qx, qy); only dereferenced where om != 0,
+                // i.e. where the blend found a pixel of that token
+                const u32 ty = y0 + slot / rw, tx = x0 + slot % rw;
+                const int tc = A.xmap[min((int)(tx * kTile), A.W - 1)] + (quad & 1);
+                const int tr = A.ymap[min((int)(ty * kTile), A.H - 1)] + (quad >> 1);
+                const long long toff = (long long)tr * A.ts_y + (long long)tc * A.ts_x;
+                const int tlo = (int)(u32)toff, thi = (int)(toff >> 32);
+                u64 todo = nz;
+                while (todo != 0ull) { // two entries' rows (2 x NC loads) in flight
+                    f4 t[2][NC];
+                    float w[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        w[u] = 0.f;
+                        if (todo != 0ull) { // wave-uniform
+                            const int l = __ffsll((long long)todo) - 1;
+                            todo &= todo - 1;
+                            w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(om), l));
+                            const long long o = ((long long)__builtin_amdgcn_readlane(thi, l) << 32) |
+                                                (long long)(u32)__builtin_amdgcn_readlane(tlo, l);
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+                                t[u][c] = *reinterpret_cast<const f4 *>(tbase + o + c * kTokCh);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (w[u] != 0.f) { // (wave-uniform; a skipped slot must not turn 0 x NaN into NaN)
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) {
+                                acc[c].x = __builtin_fmaf(w[u], t[u][c].x, acc[c].x);
+                                acc[c].y = __builtin_fmaf(w[u], t[u][c].y, acc[c].y);
+                                acc[c].z = __builtin_fmaf(w[u], t[u][c].z, acc[c].z);
+                                acc[c].w = __builtin_fmaf(w[u], t[u][c].w, acc[c].w);
+                            }
+                        }
+                }
+            }
+            if (!any)
+                break;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                fold[c].x = __builtin_fmaf(A.scale_f, acc[c].x, fold[c].x);
+                fold[c].y = __builtin_fmaf(A.scale_f, acc[c].y, fold[c].y);
+                fold[c].z = __builtin_fmaf(A.scale_f, acc[c].z, fold[c].z);
+                fold[c].w = __builtin_fmaf(A.scale_f, acc[c].w, fold[c].w);
+                __builtin_nontemporal_store(fold[c], reinterpret_cast<f4 *>(frow + c * kTokCh));
+            }
+            if (pass == 0 && A.d) { // the wave owns d[gid] as well: plain read-modify-write
+                const float tot = wave_sum(dsum);
+                if (lane == 0)
+                    A.d[gid] = __builtin_fmaf(A.scale_d, tot, A.d[gid]);
+            }
         }
     }
 }
@@ -186,19 +207,18 @@ int launch_token_apply(const Layout &L, const Ws &W, const ViewDev &V, const flo
     A.N = L.n, A.order = W.dvals[0], A.touched = W.touched, A.estart = W.dkeys[1], A.rect = W.rect;
     A.omega = reinterpret_cast<const float *>(W.headers);
     A.ymap = ymap, A.xmap = xmap, A.tokens = tokens, A.ts_y = ts_y, A.ts_x = ts_x;
-    A.D = D, A.n_chunks = D / kTokCh, A.W = V.W, A.H = V.H, A.scale_f = scale_f, A.scale_d = scale_d, A.F = F, A.d = d;
+    A.D = D, A.W = V.W, A.H = V.H, A.scale_f = scale_f, A.scale_d = scale_d, A.F = F, A.d = d;
     A.ctr = W.counters;
-    const int64_t n_groups = (L.n + kTokGroup - 1) / kTokGroup;
-    int64_t blocks;
-    if (8 % A.n_chunks == 0) {
-        const int per = 8 / A.n_chunks;
-        blocks = ((n_groups + per - 1) / per) * 8;
-    } else {
-        blocks = n_groups * A.n_chunks;
-    }
+    const int64_t blocks = (L.n + kTokGroup - 1) / kTokGroup;
     if (blocks > 0x7FFFFFFFll)
         return set_error(GWBP_EINVAL, "gwbp_scatter_tokens: grid too large");
-    hipLaunchKernelGGL(k_token_apply, dim3((unsigned)blocks), dim3(64 * kTokWaves), 0, s, A);
+    const dim3 grid((unsigned)blocks), block(64 * kTokWaves);
+    if (D % (4 * kTokCh) == 0)
+        hipLaunchKernelGGL(k_token_apply<4>, grid, block, 0, s, A);
+    else if (D % (2 * kTokCh) == 0)
+        hipLaunchKernelGGL(k_token_apply<2>, grid, block, 0, s, A);
+    else
+        hipLaunchKernelGGL(k_token_apply<1>, grid, block, 0, s, A);
     return check_hip(hipGetLastError(), "token_apply launch");
 }
 

@@ -565,7 +565,7 @@ def check_results(args, gsbp_amd, eng, views, g, pool, encoder, F_rows, d_sum, r
     err_f = float(((Fu - G[rows, 0]).abs() / scale_f).max())
     scale_d = torch.maximum(dG, 1e-6 * dG.max().clamp_min(1e-30))
     err_d = float(((d_sum.double() - dG).abs() / scale_d).max())
-    tot_d, tot_a = float(d_sum.double().sum()), float(asum)
+    tot_d, tot_a = float(d_sum.double().sum()), float(asum) * sd  # (reduction="mean": d carries the 1 / (3 H W) of backproject.py:283)
     err_c = abs(tot_d - tot_a) / max(tot_a, 1e-30)
     # The product's F and d are fp32 sums over all timed views (the reference's `gaussian_features +=` / `gaussian_denoms +=` in fp32
     # do the same), d of up to ~44 atomic adds per Gaussian and view at C1: their own accumulation error grows with the views
