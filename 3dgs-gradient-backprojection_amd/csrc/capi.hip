@@ -128,8 +128,12 @@ int make_layout(const gwbp_caps *c, Layout *L)
     L->keys[1] = take((size_t)L->isect_cap * sizeof(u32));
     L->vals[0] = take((size_t)L->isect_cap * sizeof(u32));
     L->vals[1] = take((size_t)L->isect_cap * sizeof(u32));
+#ifdef GWBP_SORT_ONESWEEP
     // two look-back status buffers [block][256 digits] of 8-B words, used alternately by the passes of a sort level
     L->hist = take((size_t)2 * 256 * L->n_sort_blocks * sizeof(u64));
+#else
+    L->hist = take((size_t)256 * L->n_sort_blocks * sizeof(u32));
+#endif
     L->digit_total = take(256 * sizeof(u32));
     L->tile_offsets = take((size_t)(L->max_tiles + 1) * sizeof(u32));
     L->tile_order = take((size_t)L->max_tiles * sizeof(u32));

@@ -10,15 +10,22 @@
 // The number of intersections lives in device memory (Counters::n_isect), so the level-2 kernels are launched for
 // the caller's capacity and idle blocks exit at once: no host read-back between projection and blend.
 //
-// Round 6 ("front diet"): per LEVEL one k_hist_all that reads the keys ONCE and produces the digit totals of every pass, then
-// ONE kernel per 8-bit pass, k_onesweep: wave-striped stable ranking (ballot "match" per digit, per-wave LDS counters) as
-// before, but a block's base inside each digit comes from a DECOUPLED LOOK-BACK over the blocks in front of it (status words
-// {flag, count} per (block, digit); blocks take their index from a ticket, so a block only ever waits for blocks that have
-// started) instead of from a per-pass histogram kernel + a scan kernel: 18 launches and three reads of the keys per pass
-// became 8 launches and (1/passes + 2) reads.  Rounds 1-5 (kept behind -DGWBP_SORT_3K for same-box A/B builds):
-//                 (1) k_hist   - per-block digit histogram, hist[digit][block]
+// Per 8-bit pass: (1) k_hist   - per-block digit histogram, hist[digit][block]
 //                 (2) k_scan   - one workgroup per digit: exclusive scan over blocks + digit total
-//                 (3) k_radix_scatter - the ranking + scatter described above, bases from (1) and (2).
+//                 (3) k_radix_scatter - wave-striped stable ranking (ballot "match" per digit, per-wave LDS
+//                                counters); only the ranks survive the barriers, keys and values are re-read for the scatter.
+//
+// Round 6 built the "front diet" the round-5 review asked for and MEASURED it against this form on one box
+// (profiles/r6_front_diet.txt): per LEVEL one k_hist_all that reads the keys once and produces the digit totals of every pass,
+// then ONE kernel per pass, k_onesweep -- the same ranking, but a block's base inside each digit comes from a DECOUPLED
+// LOOK-BACK over the blocks in front of it (status words {flag, count} per (block, digit), block index from a ticket) instead
+// of from a histogram kernel and a scan kernel: 18 sort launches per view -> 8, a third of the key reads.  Same order bit for bit
+// (the whole GPU suite passes on it), and SLOWER: every pass's 245 (depth sort) / ~880 (tile sort) blocks are resident at the
+// same time on this chip, so the look-back degenerates into a serial wavefront over the blocks -- k_onesweep 165 us per pass
+// beside the scatter kernel against 94 + 21 + 8 us for the three kernels, the C2 step 3.49-3.50 against 3.45-3.48 ms/view, C5
+// 1.33-1.36 against 1.33-1.34, alone +0.05 ms per view.  Halving the front's launches does not move the step; what the front
+// stage costs is the work of its kernels (k_blend above all), not their number.  The code stays behind -DGWBP_SORT_ONESWEEP
+// (make VARIANT=onesweep EXTRA=-DGWBP_SORT_ONESWEEP) as the record of that measurement.
 #include "gwbp_dev.h"
 
 namespace gwbp {
@@ -191,7 +198,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const u32 *__res
 }
 
 
-// ---- round 6: one histogram kernel per level + one look-back kernel per pass ---------------------------------------------------
+// ---- round 6 experiment (-DGWBP_SORT_ONESWEEP): one histogram kernel per level + one look-back kernel per pass --------------
+#ifdef GWBP_SORT_ONESWEEP
 constexpr u64 kFlagAggregate = 1ull << 32, kFlagInclusive = 2ull << 32; // status word = flag << 32 | count (counts reach 2^32 - 4096)
 
 // Digit totals of ALL passes of a level from one read of the keys: per-block LDS histograms (passes x 256 bins), non-zero bins
@@ -356,6 +364,7 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep(const u32 *__restrict
         }
     }
 }
+#endif // GWBP_SORT_ONESWEEP
 
 // Small scenes (N <= 12 K Gaussians): the whole level-1 sort -- four 8-bit passes over (depth key, index) -- in ONE
 // workgroup with the pairs resident in LDS, instead of 4 x (k_hist, k_scan, k_radix_scatter) = 12 launches of 5-15 us each.
@@ -635,7 +644,7 @@ __global__ void k_copy_u32(const u32 *__restrict__ src, int32_t *__restrict__ ds
 static void radix_passes(const Layout &L, const Ws &W, u32 *const keys[2], u32 *const vals[2], const u32 *n_dev, u32 n_host,
                          int nblk, int passes, int prio, int level, hipStream_t s)
 {
-#ifndef GWBP_SORT_3K
+#ifdef GWBP_SORT_ONESWEEP
     u64 *status[2] = {reinterpret_cast<u64 *>(W.hist), reinterpret_cast<u64 *>(W.hist) + (size_t)L.n_sort_blocks * 256};
     u32 *totals = W.sweep + level * kMaxPasses * 256;
     u32 *tickets = W.sweep + kSweepTickets + level * kMaxPasses;
@@ -647,7 +656,7 @@ static void radix_passes(const Layout &L, const Ws &W, u32 *const keys[2], u32 *
     }
     return;
 #endif
-    (void)level;
+    (void)level, (void)L;
     for (int p = 0; p < passes; ++p) {
         const int in = p & 1, out = in ^ 1;
         hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(kSortThreads), 0, s, keys[in], n_dev, n_host, p * 8, nblk, W.hist, prio);

@@ -27,6 +27,7 @@ constexpr int kTokCh = 256;       // channels per wave pass: one float4 per lane
 constexpr int kTokPerWave = 16;   // Gaussians (consecutive in depth order) per wave
 constexpr int kTokWaves = 4;
 constexpr int kTokGroup = kTokPerWave * kTokWaves; // Gaussians per workgroup
+constexpr int kTokMaxTiles = 1024;                 // tile columns / rows of the largest view the token path takes (16 384 px)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -65,6 +66,15 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
             atomicOr(&A.ctr->overflow, kOverflowMismatch);
         return;
     }
+    // first token column / row of every tile column / row (the index maps at the tiles' first pixels): a few hundred ints that
+    // every entry's token lookup reads -- from LDS, not through a dependent global load in front of the token row reads
+    __shared__ int s_tc0[kTokMaxTiles], s_tr0[kTokMaxTiles];
+    const int tile_w = (A.W + kTile - 1) / kTile, tile_h = (A.H + kTile - 1) / kTile;
+    for (int i = threadIdx.x; i < tile_w; i += 64 * kTokWaves)
+        s_tc0[i] = A.xmap[min(i * kTile, A.W - 1)];
+    for (int i = threadIdx.x; i < tile_h; i += 64 * kTokWaves)
+        s_tr0[i] = A.ymap[min(i * kTile, A.H - 1)];
+    __syncthreads();
     const int lane = (int)(threadIdx.x & 63u), wave = (int)uniform(threadIdx.x >> 6);
     const int64_t i0 = (int64_t)blockIdx.x * kTokGroup + wave * kTokPerWave;
     if (i0 >= A.N)
@@ -128,8 +138,8 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                 // the token under this lane's (tile, quadrant): first token of the tile + (qx, qy); only dereferenced where om != 0,
                 // i.e. where the blend found a pixel of that token
                 const u32 ty = y0 + slot / rw, tx = x0 + slot % rw;
-                const int tc = A.xmap[min((int)(tx * kTile), A.W - 1)] + (quad & 1);
-                const int tr = A.ymap[min((int)(ty * kTile), A.H - 1)] + (quad >> 1);
+                const int tc = s_tc0[min(tx, (u32)tile_w - 1u)] + (quad & 1);
+                const int tr = s_tr0[min(ty, (u32)tile_h - 1u)] + (quad >> 1);
                 const long long toff = (long long)tr * A.ts_y + (long long)tc * A.ts_x;
                 const int tlo = (int)(u32)toff, thi = (int)(toff >> 32);
                 u64 todo = nz;
@@ -201,6 +211,9 @@ int launch_token_apply(const Layout &L, const Ws &W, const ViewDev &V, const flo
         (reinterpret_cast<uintptr_t>(F) & 15))
         return set_error(GWBP_EINVAL, "gwbp_scatter_tokens: token rows must be 16-B aligned runs of D contiguous channels "
                                       "(strides %lld %lld), F 16-B aligned", (long long)ts_y, (long long)ts_x);
+    if (V.tile_w > kTokMaxTiles || V.tile_h > kTokMaxTiles)
+        return set_error(GWBP_EUNSUPPORTED, "gwbp_scatter_tokens: views of more than %d tile columns / rows are not supported",
+                         kTokMaxTiles);
     if (L.n == 0)
         return GWBP_OK;
     TokenApplyArgs A;
