@@ -81,6 +81,7 @@ class Stats(C.Structure):
 FLAG_TIGHT_BINNING = 1  # GWBP_FLAG_TIGHT_BINNING (include/gwbp.h)
 FLAG_FRONT_PRIORITY = 2  # GWBP_FLAG_FRONT_PRIORITY
 FLAG_NARROW_SCATTER = 4  # GWBP_FLAG_NARROW_SCATTER
+FLAG_SPLIT_ENCODER = 16  # GWBP_FLAG_SPLIT_ENCODER
 
 
 class GwbpError(RuntimeError):

@@ -170,7 +170,7 @@ class ViewPipeline:
     def __init__(self, n_gaussians, width, height, device, engines=None, scatter_dim: Optional[int] = None,
                  allow_wide: bool = True, scatter_workgroups: Optional[int] = None, side_priority: int = -1,
                  front_priority: Optional[bool] = None, fuse_small: bool = True, side_streams: Optional[int] = None,
-                 view_per_stream: Optional[bool] = None, token_grid=None):
+                 view_per_stream: Optional[bool] = None, token_grid=None, split_encoder: bool = False):
         self.dev = torch.device(device)
         # token_grid = (h, w): the views' feature maps are h x w maps upsampled with mode="nearest" whose texels are at least a
         # tile wide and high (the dino variant's 64 x 64 patch tokens): the front stage ends with Engine.blend_tokens (per-record
@@ -213,6 +213,11 @@ class ViewPipeline:
         self.fuse_small = (bool(fuse_small) and scatter_dim is not None and self.token_grid is None
                            and scatter_dim <= Engine.fused_max_dim(width, height)
                            and (small_image or len(self.eng) == 2 or bool(view_per_stream)))
+        # split_encoder: blend_scatter_encoded in its producer / consumer form (GWBP_FLAG_SPLIT_ENCODER: one persistent launch per
+        # view whose encoder waves and blend waves run concurrently; the compressed variant on large images)
+        self.split_encoder = bool(split_encoder)
+        for e in self.eng:
+            e.set_split_encoder(self.split_encoder)
         self.front_priority = front_priority  # None: raised wave priority for the front exactly when the wide kernel runs
         self.choose_scatter_kernel(None, None)
         K = len(self.eng)
@@ -469,6 +474,10 @@ class ViewPipeline:
         return out
 
 
+# images of at least this many 16 x 16 tiles run the compressed variant's fused kernel in its producer / consumer form by default
+# (create_feature_field(encoder_split=None)): 16 tiles per CU on MI355X, below which the ring's start-up and tail outweigh the overlap
+SPLIT_ENCODER_MIN_TILES = 4096
+
 # create_feature_field looks at the accumulated overflow flags after view 2 and then every this many views (a non-blocking
 # copy of the counters, read back a few views later): a capacity overflow in view 150 of 200 restarts the job after at most
 # this many more views instead of after the last one
@@ -506,7 +515,8 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                          return_partials: bool = False, verbose: bool = False, upsample: Optional[str] = None,
                          gather: bool = True, allow_wide: bool = True, fuse_encoder: bool = False,
                          fuse_small: bool = True, feature_fn_stream_safe: bool = False,
-                         encoder_in_blend: Optional[bool] = None, token_space: bool = True):
+                         encoder_in_blend: Optional[bool] = None, token_space: bool = True,
+                         encoder_split: Optional[bool] = None):
     """Build the [N, dim_out] per-Gaussian feature field.
 
     means/quats/scales/opacities: post-activation Gaussians (backproject.py:55-57), device tensors.
@@ -528,6 +538,9 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     one kernel per view, no [H,W,dim_out] map, four views in flight on streams of their own).  None (default) = whenever the
     first map's layout allows and fuse_small is on (C5: 1.27-1.33 against 1.38-1.44 ms/view for the encoder one view ahead);
     False = never.
+    encoder_split: with encoder_in_blend, run that kernel in its producer / consumer form (GWBP_FLAG_SPLIT_ENCODER: one persistent
+    launch per view, encoder waves and blend waves around an LDS ring of encoded tiles).  None (default) = on images of at least
+    SPLIT_ENCODER_MIN_TILES tiles, where a CU's encoder waves have tiles enough to stream; False = never.
     token_space: with upsample="nearest", maps whose texels are at least a 16 x 16 tile wide and high and whose channel count is a
     multiple of 256 (the dino variant's 64 x 64 x 1024 patch tokens at 1600 x 1060) are back-projected in TOKEN space: the blend
     leaves per-(Gaussian, tile) weight sums of the tile's 2 x 2 tokens and every F row that receives weight is updated with ONE
@@ -591,7 +604,9 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                              and encoder_in_blend is not False and Engine.can_blend_scatter_encoded(first_map, encoder))
                 depth = (pipeline_depth(n, width, height, d_out, encoder_in_blend=enc_blend) if pipeline is True
                          else max(2, int(pipeline)))
-                pipe = ViewPipeline(n, width, height, dev, scatter_dim=d_out, token_grid=token_grid,
+                split = bool(enc_blend and (encoder_split if encoder_split is not None
+                                            else (-(-width // 16)) * (-(-height // 16)) >= SPLIT_ENCODER_MIN_TILES))
+                pipe = ViewPipeline(n, width, height, dev, scatter_dim=d_out, token_grid=token_grid, split_encoder=split,
                                     allow_wide=allow_wide, fuse_small=fuse_small and not (fuse_encoder and encoder is not None),
                                     view_per_stream=True if (enc_blend and depth > 2) else None,
                                     engines=[eng] + [Engine(n, width, height, device=dev, tight_binning=eng.tight_binning,

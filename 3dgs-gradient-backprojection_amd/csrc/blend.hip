@@ -48,10 +48,24 @@ constexpr int kBatch = 64;
 //            order of its tile rectangle; estart[gid] is where they start) -- so the weight sums of one Gaussian lie back to back
 //            whatever tiles they came from, and k_token_apply (token.hip) adds them to F with ONE plain read-modify-write of the
 //            row per view: no pair entries, no headers, no atomics, no slabs, no carry rows.
-enum BlendMode { kStore = 0, kHalves = 1, kFused = 2, kFusedEnc = 3, kToken = 4 };
+//   kFusedPC: kFusedEnc split into PRODUCER and CONSUMER waves inside one persistent launch (round 6; the compressed variant,
+//            backproject_compressed.py:127-165).  kFusedEnc runs every wave's HBM-bound encoder prologue (0.58 ms worth at C5) and
+//            then its issue-bound blend loop (0.70 ms) back to back, and since all resident waves start together the chip
+//            alternates between an HBM phase with idle issue slots and an issue phase with an idle memory system.  Here one
+//            workgroup per CU holds kPcProd encoder waves (one per SIMD) that do nothing but stream tiles through the matrix
+//            cores into a ring of encoded tiles in LDS (16 KB each), and WAVES - kPcProd blend waves that drain it: the HBM stream
+//            and the blend loops run CONCURRENTLY for the whole launch.  Same encoded pixels, same weights, bit for bit.
+enum BlendMode { kStore = 0, kHalves = 1, kFused = 2, kFusedEnc = 3, kToken = 4, kFusedPC = 5 };
 constexpr int kFusedCh = 16;
 constexpr int kEncWaves = 8;    // kFusedEnc: tiles (waves) per workgroup sharing one LDS copy of the encoder
 constexpr int kEncMaxK = 512;   // ... whose K x 16 floats take at most 32 KB
+constexpr int kPcWaves = 12;    // kFusedPC: waves per workgroup (one workgroup per CU: three 128-register waves per SIMD, which leaves
+                                // every SIMD room for one front-stage wave of another view)
+constexpr int kPcProd = 4;      // ... of which the first four -- one per SIMD -- are encoder (producer) waves
+constexpr int kPcRing = 6;      // ... filling a ring of this many encoded tiles (256 pixels x 16 outputs x 4 B = 16 KB each) in LDS
+constexpr int kPcTileFloats = kTilePix * kFusedCh;
+// ring slot states: 0 = empty, 1 = claimed (being filled or being read), tile + 2 = holds that tile's encoded pixels
+constexpr u32 kPcEmpty = 0u, kPcBusy = 1u;
 
 struct FusedArgs { // kFused only
     const float *feats; // feats[y * fs_y + x * fs_x + c], c < D
@@ -67,6 +81,8 @@ struct FusedArgs { // kFused only
     float *omega;               // [isect_cap][4]: weight sums per (emit position, token quadrant qx | qy << 1), zeroed per view
     const u32 *estart;          // first emit position of every Gaussian (k_emit)
     const uint2 *rect;          // the tile rectangle the emit walked (k_project)
+    // kFusedPC only
+    u32 *pc_queue;              // next tile (index into tile_order) a producer wave takes; zero when the kernel starts
 };
 
 
@@ -218,6 +234,67 @@ __device__ __forceinline__ void rows_transpose4(float (&x)[4])
 #endif
 }
 
+
+// One quarter (4 tile rows x 16 pixels) of a tile through the encoder on the matrix cores: R[rho][r] of lane (column, g) becomes
+// output 4 g + r of the pixel (column, row 4 q + rho).  One MFMA tile = ONE TILE ROW: M = the 16 encoder outputs (A operand: lane
+// (n = lane % 16, kq = lane / 16) reads its encoder value from LDS), N = the row's 16 pixels (B operand: lane (column, kq) holds the
+// float4 feats[pixel][16 j + 4 kq ..] of k-block j, component i feeds step i); the four rows are accumulated side by side, so
+// the four encoder reads of a k-block serve 16 MFMAs.  PF k-blocks (PF x 4 rows x 16 B per lane) are in flight.
+// address = wave-uniform row base (scalar registers) + ONE per-lane byte offset: four 64-bit pointers per lane would cost eight
+// registers of the 128 the kernel may use.
+template <int PF>
+__device__ __forceinline__ void encode_quarter(const float *feats, int64_t fs_y, int H, int ty, int q, u32 lane_off, int nb,
+                                               const float *ebase, f32x4m (&R)[4])
+{
+    const char *rowp[4];
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho)
+        rowp[rho] = reinterpret_cast<const char *>(feats + (int64_t)min(ty * kTile + 4 * q + rho, H - 1) * fs_y);
+    auto ld = [&](int rho, int j) __attribute__((always_inline)) -> float4 {
+        return *reinterpret_cast<const float4 *>(rowp[rho] + ((size_t)lane_off + (size_t)(64 * j)));
+    };
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho)
+        R[rho] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    float4 b[PF][4];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho)
+            b[u][rho] = ld(rho, min(u, nb - 1));
+    for (int j0 = 0; j0 < nb; j0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int j = j0 + u;
+            if (j >= nb)
+                break;
+            float4 bv[4];
+#pragma unroll
+            for (int rho = 0; rho < 4; ++rho)
+                bv[rho] = b[u][rho];
+            if (j + PF < nb) {
+#pragma unroll
+                for (int rho = 0; rho < 4; ++rho)
+                    b[u][rho] = ld(rho, j + PF);
+            }
+            const float *e = ebase + j * 256; // (kq, n) = lane; steps i are 64 floats apart
+            const float a0 = e[0], a1 = e[64], a2 = e[128], a3 = e[192];
+#pragma unroll
+            for (int rho = 0; rho < 4; ++rho)
+                R[rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[rho].x, R[rho], 0, 0, 0);
+#pragma unroll
+            for (int rho = 0; rho < 4; ++rho)
+                R[rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[rho].y, R[rho], 0, 0, 0);
+#pragma unroll
+            for (int rho = 0; rho < 4; ++rho)
+                R[rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bv[rho].z, R[rho], 0, 0, 0);
+#pragma unroll
+            for (int rho = 0; rho < 4; ++rho)
+                R[rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bv[rho].w, R[rho], 0, 0, 0);
+        }
+    }
+}
+
 template <int MODE, int WAVES = 1>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_blend(ViewDev V, const u32 *__restrict__ tile_offsets,
                                               const u32 *__restrict__ vals, const G2D *__restrict__ g2d,
@@ -234,457 +311,529 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
     (void)dbg_arg;
 #endif
     constexpr bool WSUM = MODE == kHalves; // the record's weight sum in its header (+ d[gid] right here)
-    constexpr bool FUSED = MODE == kFused || MODE == kFusedEnc;
+    constexpr bool PC = MODE == kFusedPC;
+    constexpr bool FUSED = MODE == kFused || MODE == kFusedEnc || PC;
     constexpr bool TOKEN = MODE == kToken;
+    constexpr int BW = PC ? WAVES - kPcProd : WAVES; // waves that blend (and own a staging area)
     front_priority(prio);
-    __shared__ float4 s_a_[WAVES][kBatch]; // mx, my, opac, gid bits
-    __shared__ float4 s_b_[WAVES][kBatch]; // ca, cb, cc, strip mask
-    __shared__ float s_thr_[WAVES][kBatch]; // ln(255 o) + margin: sigma above this cannot reach alpha >= 1/255
+    __shared__ float4 s_a_[BW][kBatch]; // mx, my, opac, gid bits
+    __shared__ float4 s_b_[BW][kBatch]; // ca, cb, cc, strip mask
+    __shared__ float s_thr_[BW][kBatch]; // ln(255 o) + margin: sigma above this cannot reach alpha >= 1/255
     __shared__ u32 s_pos_[TOKEN ? WAVES : 1][TOKEN ? kBatch : 1]; // kToken: emit position of the (Gaussian, tile) pair
     const int wave = WAVES > 1 ? (int)uniform(threadIdx.x >> 6) : 0;
-    float4 *const s_a = s_a_[wave], *const s_b = s_b_[wave];
-    float *const s_thr = s_thr_[wave];
+    const int bw = PC ? max(wave - kPcProd, 0) : wave;
+    float4 *const s_a = s_a_[bw], *const s_b = s_b_[bw];
+    float *const s_thr = s_thr_[bw];
     u32 *const s_pos = s_pos_[TOKEN ? wave : 0];
+    const int lane = (int)(threadIdx.x & 63u);
 
     const int n_tiles_all = V.tile_w * V.tile_h;
     const int slot = (int)blockIdx.x * WAVES + wave;
-    if constexpr (MODE == kFusedEnc) {
+    // kFusedPC: dynamic LDS = encoder | ring of kPcRing encoded tiles | ring states + number of producers that have finished
+    float *pc_ring = nullptr;
+    u32 *pc_state = nullptr;
+    if constexpr (MODE == kFusedEnc || PC) {
         // the encoder, re-ordered per MFMA step like k_encode_map's: [K/16][i][kq][n] <- enc[16 j + 4 kq + i][n]
         extern __shared__ __attribute__((aligned(16))) float s_enc[];
         for (int idx = threadIdx.x; idx < fu.enc_k * kFusedCh; idx += 64 * WAVES) {
             const int n = idx & 15, kq = (idx >> 4) & 3, i = (idx >> 6) & 3, j = idx >> 8;
             s_enc[idx] = n < fu.D ? fu.enc[(int64_t)(16 * j + 4 * kq + i) * fu.D + n] : 0.f;
         }
+        if constexpr (PC) {
+            pc_ring = s_enc + fu.enc_k * kFusedCh;
+            pc_state = reinterpret_cast<u32 *>(pc_ring + kPcRing * kPcTileFloats);
+            if (threadIdx.x <= kPcRing)
+                pc_state[threadIdx.x] = 0u; // kPcRing slot states + the finished-producers count
+        }
         __syncthreads();
     }
-    if (WAVES > 1 && slot >= n_tiles_all)
-        return; // (behind the only barrier of the kernel: the waves of a workgroup are independent from here on)
-    const int tile = (int)tile_order[slot]; // longest lists first
-    const int tx = tile % V.tile_w, ty = tile / V.tile_w;
-    const int lane = (int)(threadIdx.x & 63u);
-    const int ix = tx * kTile + (lane & 15), iy0 = ty * kTile + (lane >> 4);
-    const float px = (float)ix + 0.5f;
-    const u32 beg = tile_offsets[tile], end = tile_offsets[tile + 1];
-
-    // The weight pool is carved into kShards regions with their own head words: a single head saturates at
-    // ~88 returning same-address atomics per microsecond, which cost 1.0 ms/view with ~96 K page grabs per view.
-    const u32 shard = (u32)tile % (u32)kShards;
-    const u32 shard_cap = (pair_cap / (u32)kShards) & ~(u32)(kPage - 1);
-    const u32 shard_base = shard * shard_cap;
-    u32 *shard_head = shards + shard * 16;
-
-    // Per-pixel state.  T = 0 encodes "terminated or outside the image": a pixel with T = 0 can never produce a valid
-    // pair again (T (1 - alpha) = 0 <= 1e-4), so no separate done flag -- and none of the scalar mask bookkeeping a
-    // bool per lane costs (the first version of this loop issued more SALU than VALU instructions).  Tout keeps the
-    // transmittance to report (1 - Tout = alpha map), which the terminating Gaussian must not change.
-    float T[4], Tout[4], py[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int iy = iy0 + 4 * q;
-        py[q] = (float)iy + 0.5f;
-        T[q] = (ix < V.W && iy < V.H) ? 1.0f : 0.0f;
-        Tout[q] = 1.0f;
-    }
-    u32 page_pos = 0, page_left = 0, npairs = 0, hdr_n = 0, span_n = 0; // wave-uniform
-    bool dead = false;                                     // wave-uniform: pool exhausted
-
-    // kToken: which of the tile's (at most) 2 x 2 tokens a pixel falls into, as lane masks: cmask = lanes whose column lies in the
-    // tile's SECOND token column, rmask[q] = lanes whose row 4 q + lane / 16 lies in its second token row.  The nearest index maps
-    // are non-decreasing; a tile that spans more than two token columns or rows (texels narrower than a tile) violates the entry
-    // point's precondition and raises overflow bit 3 -- the host never takes this path for such maps.
-    u64 cmask = 0ull, rmask[4] = {0ull, 0ull, 0ull, 0ull};
-    if constexpr (TOKEN) {
-        const int c_rel = fu.xmap[min(ix, V.W - 1)] - fu.xmap[min(tx * kTile, V.W - 1)];
-        cmask = __ballot(c_rel >= 1);
-        bool wide = c_rel > 1 || c_rel < 0;
-        const int r_base = fu.ymap[min(ty * kTile, V.H - 1)];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r_rel = fu.ymap[min(iy0 + 4 * q, V.H - 1)] - r_base;
-            rmask[q] = __ballot(r_rel >= 1);
-            wide |= r_rel > 1 || r_rel < 0;
-        }
-        if (__ballot(wide) != 0ull && lane == 0)
-            atomicOr(&ctr->overflow, kOverflowTokenGeometry);
-    }
-
-    // kFused: the lane's four pixels, kFusedCh channels each, stay in registers for the whole tile (pixels outside the
-    // image never get a weight: T = 0; they read a clamped address)
-    float f[FUSED ? 4 : 1][FUSED ? kFusedCh : 1];
-    if constexpr (MODE == kFusedEnc) {
-        // f[q][c] = sum_k feats[pixel (ix, iy0 + 4 q)][k] enc[k][c].  One MFMA tile = ONE TILE ROW: M = the 16 encoder outputs
-        // (A operand: lane (n = lane % 16, kq = lane / 16) reads its encoder value from LDS), N = the row's 16 pixels (B operand:
-        // lane (column = lane % 16, kq) holds the float4 feats[pixel][16 j + 4 kq ..] of k-block j, component i feeds step i),
-        // so the result registers of lane (column, g) are outputs 4 g .. 4 g + 3 of that row's pixel in ITS column.  Four
-        // rows (one quarter) are accumulated side by side -- the four encoder reads of a k-block serve 16 MFMAs -- and a
-        // 4 x 4 exchange between the lane rows hands every lane all 16 outputs of its own pixel (row 4 q + lane / 16).
-        extern __shared__ __attribute__((aligned(16))) float s_enc[];
-        const int kq = lane >> 4;
-        const int cx = min(ix, V.W - 1);
-        const int nb = fu.enc_k >> 4;
-        const float *ebase = s_enc + lane;
-        // address = wave-uniform row base (scalar registers) + ONE per-lane byte offset: four 64-bit pointers per lane would cost
-        // eight registers of the 128 the kernel may use at four waves per SIMD
-        const u32 lane_off = (u32)(((int64_t)cx * fu.fs_x + 4 * kq) * (int64_t)sizeof(float));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const char *rowp[4];
-#pragma unroll
-            for (int rho = 0; rho < 4; ++rho)
-                rowp[rho] = reinterpret_cast<const char *>(fu.feats + (int64_t)min(ty * kTile + 4 * q + rho, V.H - 1) * fu.fs_y);
-            auto ld = [&](int rho, int j) __attribute__((always_inline)) -> float4 {
-                return *reinterpret_cast<const float4 *>(rowp[rho] + ((size_t)lane_off + (size_t)(64 * j)));
-            };
-            f32x4m R[4];
-#pragma unroll
-            for (int rho = 0; rho < 4; ++rho)
-                R[rho] = f32x4m{0.f, 0.f, 0.f, 0.f};
-            constexpr int kPF = 2; // k-blocks in flight: 2 x 4 rows x 16 B per lane = 8 KB per wave
-            float4 b[kPF][4];
-#pragma unroll
-            for (int u = 0; u < kPF; ++u)
-#pragma unroll
-                for (int rho = 0; rho < 4; ++rho)
-                    b[u][rho] = ld(rho, min(u, nb - 1));
-            for (int j0 = 0; j0 < nb; j0 += kPF) {
-#pragma unroll
-                for (int u = 0; u < kPF; ++u) {
-                    const int j = j0 + u;
-                    if (j >= nb)
-                        break;
-                    float4 bv[4];
-#pragma unroll
-                    for (int rho = 0; rho < 4; ++rho)
-                        bv[rho] = b[u][rho];
-                    if (j + kPF < nb) {
-#pragma unroll
-                        for (int rho = 0; rho < 4; ++rho)
-                            b[u][rho] = ld(rho, j + kPF);
-                    }
-                    const float *e = ebase + j * 256; // (kq, n) = lane; steps i are 64 floats apart
-                    const float a0 = e[0], a1 = e[64], a2 = e[128], a3 = e[192];
-#pragma unroll
-                    for (int rho = 0; rho < 4; ++rho)
-                        R[rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[rho].x, R[rho], 0, 0, 0);
-#pragma unroll
-                    for (int rho = 0; rho < 4; ++rho)
-                        R[rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[rho].y, R[rho], 0, 0, 0);
-#pragma unroll
-                    for (int rho = 0; rho < 4; ++rho)
-                        R[rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bv[rho].z, R[rho], 0, 0, 0);
-#pragma unroll
-                    for (int rho = 0; rho < 4; ++rho)
-                        R[rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bv[rho].w, R[rho], 0, 0, 0);
-                }
-            }
-            // R[rho][r] of lane row g = output 4 g + r of the pixel (column, row 4 q + rho)  ->  f[q][4 g + r] of lane row rho
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x[4] = {R[0][r], R[1][r], R[2][r], R[3][r]};
-                rows_transpose4(x);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    f[q][4 * g + r] = x[g];
-            }
-        }
-    }
-    if constexpr (MODE == kFused) {
-        const int cx = min(ix, V.W - 1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float *src = fu.feats + (int64_t)min(iy0 + 4 * q, V.H - 1) * fu.fs_y + (int64_t)cx * fu.fs_x;
-            if (fu.vec4) {
-#pragma unroll
-                for (int c4 = 0; c4 < kFusedCh / 4; ++c4) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (4 * c4 < fu.D)
-                        v = reinterpret_cast<const float4 *>(src)[c4];
-                    f[q][4 * c4] = v.x, f[q][4 * c4 + 1] = v.y, f[q][4 * c4 + 2] = v.z, f[q][4 * c4 + 3] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < kFusedCh; ++c)
-                    f[q][c] = c < fu.D ? src[c] : 0.f;
-            }
-        }
-    }
-    // A non-finite feature value (backproject.py:109: feats / feats.norm() of an all-zero pixel is NaN) must reach exactly the
-    // Gaussians that have a weight AT that pixel -- the reference's backward adds fac * v_render for contributing pairs only.
-    // The record sums below multiply a lane's pixels by a weight that is 0 where the record has no entry, and 0 x NaN is NaN,
-    // which poisoned every record of the tile (found in round 5; the vector scatter kernels had been fixed in round 3).
-    // Once per tile: bad[q] = lanes whose pixel of quarter q holds a non-finite value (scalar masks), those pixels are zeroed
-    // in the registers, and a record whose entry mask meets bad[] gets NaN sums instead -- a few scalar instructions per
-    // record, no vector work in tiles without such pixels.  (All channels of the record become NaN, also where the reference
-    // would keep a finite or infinite one: the row is non-finite either way, and backproject.py:166-169 maps it to zeros.)
-    u64 bad[4] = {0ull, 0ull, 0ull, 0ull};
-    if constexpr (FUSED) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float chk = 0.f;
-#pragma unroll
-            for (int c = 0; c < kFusedCh; ++c)
-                chk = __builtin_fmaf(f[q][c], 0.f, chk); // NaN iff some value is NaN or +-inf
-            bad[q] = __ballot(chk != chk);
-            if (bad[q] != 0ull) { // (wave-uniform, rare)
-#pragma unroll
-                for (int c = 0; c < kFusedCh; ++c)
-                    f[q][c] = (chk != chk) ? 0.f : f[q][c];
-            }
-        }
-    }
-    // per-lane constants of the record flush: lanes 0..15 add channel transposed_channel(lane) of F[gid], lane 16 adds d[gid]
-    const int my_ch = transposed_channel(lane);
-    float *out_base = nullptr;
-    size_t out_mul = 0;
-    float out_scale = 0.f;
-    bool out_on = false;
-    if constexpr (FUSED) {
-        out_base = lane < 16 ? fu.F + my_ch : d_out;
-        out_mul = lane < 16 ? (size_t)fu.D : (size_t)1;
-        out_scale = lane < 16 ? fu.scale_f : scale_d;
-        out_on = lane < 16 ? my_ch < fu.D : (lane == 16 && d_out != nullptr);
-    }
-
-    for (u32 batch = beg; batch < end; batch += kBatch) {
-        // quarters that still have a live pixel; stop when the whole tile has terminated (gsplat: all threads done)
-        u32 alive = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            alive |= (__ballot(T[q] > 0.f) != 0ull ? 1u : 0u) << q;
-        if (alive == 0)
-            break;
-        const u32 bn = min((u32)kBatch, end - batch);
-        if ((u32)lane < bn) {
-            const u32 gid = vals[batch + lane];
-            const float4 *gp = reinterpret_cast<const float4 *>(g2d + gid);
-            const float4 a = gp[0], b = gp[1];
-            // Conservative strip mask: bit q set <=> the Gaussian MAY reach alpha >= 1/255 somewhere in tile rows
-            // 4q..4q+3.  For a fixed dy the minimum of sigma over dx is dy^2 / (2 Syy) (Syy = ca / det(conic)), so a
-            // row with dy^2 > 2 Syy ln(255 o) cannot contribute; same in x for the whole tile.  Distances carry a
-            // 5 % + 1 px margin (>> fp32 error of sigma: conic entries are bounded by 1/eps2d), so a rejected
-            // (Gaussian, strip) provably has no contributing pixel and results are unchanged bit for bit.
-            u32 smask = 0;
-            const float L = __logf(255.0f * a.z); // ln(255 o); o <= 1/255 can never reach alpha >= 1/255
-            if (L > 0.f) {
-                const float idet = 1.0f / (b.x * b.z - b.y * b.y);
-                const float ex = 1.05f * __builtin_sqrtf(2.0f * L * b.z * idet) + 1.0f;
-                const float ey = 1.05f * __builtin_sqrtf(2.0f * L * b.x * idet) + 1.0f;
-                const float x0 = (float)(tx * kTile) + 0.5f, y0 = (float)(ty * kTile) + 0.5f;
-                const bool xhit = !(a.x + ex < x0 || a.x - ex > x0 + 15.0f);
-                if (xhit) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float ya = y0 + 4.0f * q;
-                        const bool miss = (a.y + ey < ya) || (a.y - ey > ya + 3.0f);
-                        smask |= (miss ? 0u : 1u) << q;
-                    }
-                }
-                if (!(ex == ex) || !(ey == ey))
-                    smask = 0xFu; // degenerate conic: never reject
-            }
-            s_a[lane] = make_float4(a.x, a.y, a.z, __int_as_float((int)gid));
-            s_b[lane] = make_float4(b.x, b.y, b.z, __int_as_float((int)smask));
-            // alpha = o exp(-sigma) >= 1/255  <=>  sigma <= ln(255 o); 1e-3 absorbs the error of __logf and exp_neg
-            s_thr[lane] = L + 1e-3f;
-            if constexpr (TOKEN) { // this (Gaussian, tile) pair's emit position: k_emit walked the rectangle row-major from estart
-                const uint2 rc = fu.rect[gid];
-                const u32 rx0 = rc.x & 0xFFFFu, rx1 = rc.x >> 16, ry0 = rc.y & 0xFFFFu;
-                s_pos[lane] = fu.estart[gid] + ((u32)ty - ry0) * (rx1 - rx0) + ((u32)tx - rx0);
-            }
-        }
-        // single wave: LDS operations of one wave complete in program order, no barrier needed
-
-        for (u32 j = 0; j < bn && !(dbg & 2); ++j) {
-            const float4 b = s_b[j];
-            const u32 sm = uniform((u32)__float_as_int(b.w)) & alive;
-            if (sm == 0)
-                continue; // this Gaussian cannot reach any live quarter of the tile
-            const float4 a = s_a[j];
-            const float thr = s_thr[j];
-            const float dx = a.x - px;
-            const float adx = b.x * dx, bdx = b.y * dx; // shared by the four quarters (same column)
-            u64 m[4];
-            float w[4];
-            // Per-lane control flow is branch-free and flag-free (float selects); the only branches are wave-uniform.
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                m[q] = 0ull, w[q] = 0.f;
-                if ((sm >> q) & 1u) {
-                    const float dy = a.y - py[q];
-                    const float sigma = __builtin_fmaf(bdx, dy, 0.5f * __builtin_fmaf(adx, dx, (b.z * dy) * dy));
-                    // no live pixel of this quarter lies inside the alpha >= 1/255 ellipse: skip exp / T / ballot
-                    if (__ballot(T[q] > 0.f && sigma <= thr) == 0ull)
-                        continue;
-                    const float alpha = __builtin_fminf(kAlphaMax, a.z * exp_neg_sigma(sigma));
-                    // The three tests as lane masks (a ballot of a COMPARE is that compare's own SGPR result; a ballot of
-                    // their conjunction costs v_cndmask + v_cmp_ne), combined on the scalar unit.
-                    const float next_T = T[q] * (1.0f - alpha);
-                    const u64 m_ok = __builtin_amdgcn_ballot_w64(sigma >= 0.f) &       // sigma < 0: skipped
-                                     __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin);  // alpha < 1/255: skipped
-                    const u64 m_valid = m_ok & __builtin_amdgcn_ballot_w64(next_T > kTMin); // T' <= 1e-4: terminates, NOT counted
-                    const float T_else = mask_select(m_ok, 0.f, T[q]);       // ok but not valid -> terminated
-                    w[q] = alpha * T[q];
-                    T[q] = mask_select(m_valid, next_T, T_else);
-                    Tout[q] = mask_select(m_valid, next_T, Tout[q]);
-                    m[q] = m_valid;
-                }
-            }
-            if ((m[0] | m[1] | m[2] | m[3]) == 0ull) {
-                // a quarter may have died without contributing: refresh the live set lazily
-                if ((j & 7u) == 7u) {
-                    alive = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        alive |= (__ballot(T[q] > 0.f) != 0ull ? 1u : 0u) << q;
-                    if (alive == 0)
-                        break;
-                }
-                continue;
-            }
-            // Entry layout of a record: quarters 0 | 1 back to back, then quarters 2 | 3 back to back.  kHalves: the second half
-            // starts on a multiple of kListPad entries (64 B), i.e. BOTH half-tile lists are padded -- k_scatter_wide fetches a
-            // half's entries eight at a time with s_load_dwordx16 and must find {0, kPadPix} behind the last real one.
-            u32 cnt[4], base[4], total = 0, mid_pad = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                cnt[q] = (u32)__popcll(m[q]);
-                if (WSUM && q == 2) {
-                    mid_pad = (0u - total) & (u32)(kListPad - 1);
-                    total += mid_pad;
-                }
-                base[q] = total;
-                total += cnt[q];
-            }
-            if constexpr (TOKEN) {
-                // the record's four token-quadrant weight sums (index qx | qy << 1), one 16-B line at its emit position
-                float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (m[q] != 0ull) { // wave-uniform
-                        const float wq = mask_select(m[q], w[q], 0.f);
-                        a1 += mask_select(rmask[q], wq, 0.f);
-                        a0 += mask_select(rmask[q], 0.f, wq);
-                    }
-                const float r = transposed_sum4(mask_select(cmask, 0.f, a0), mask_select(cmask, a0, 0.f),
-                                                mask_select(cmask, 0.f, a1), mask_select(cmask, a1, 0.f));
-                if (!(dbg & 1) && lane < 4)
-                    fu.omega[(size_t)s_pos[j] * 4 + lane] = r;
-                ++hdr_n;
-                npairs += total;
-                continue;
-            }
-            if constexpr (FUSED) {
-                float p[kFusedCh], wl = 0.f;
-#pragma unroll
-                for (int c = 0; c < kFusedCh; ++c)
-                    p[c] = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (m[q] != 0ull) { // wave-uniform
-                        const float wq = mask_select(m[q], w[q], 0.f); // the ballot register is the select mask
-                        wl += wq;
-#pragma unroll
-                        for (int c = 0; c < kFusedCh; ++c)
-                            p[c] = __builtin_fmaf(wq, f[q][c], p[c]);
-                    }
-                float tot = transposed_sum16(p); // every row: channel my_ch
-                if (((m[0] & bad[0]) | (m[1] & bad[1]) | (m[2] & bad[2]) | (m[3] & bad[3])) != 0ull) // (scalar; see bad[] above)
-                    tot = __builtin_nanf("");
-                wl += dpp_get<0xB1>(wl);
-                wl += dpp_get<0x4E>(wl);
-                wl += dpp_get<0x141>(wl);
-                wl += dpp_get<0x140>(wl);
-                const float ws = rows_sum(wl);
-                if (!(dbg & 1) && out_on) {
-                    // one atomic instruction: lanes 0..15 the record's channel sums, lane 16 its share of d
-                    const u32 gid = (u32)__float_as_int(a.w);
-                    atomicAdd(out_base + (size_t)gid * out_mul, (lane < 16 ? tot : ws) * out_scale);
-                }
-                ++hdr_n;
-                npairs += total;
-                continue;
-            }
-            const u32 padded = (total + (kListPad - 1)) & ~(u32)(kListPad - 1);
-            const u32 end_pad = padded - total;
-            if (padded > page_left) {
-                u32 old = 0;
+    if constexpr (PC) {
+        if (wave < kPcProd) {
+            // ---- producer wave: claim a tile (heaviest first, one global counter), claim an empty ring slot, stream the tile's
+            // 256 pixels x K channels through the matrix cores into it, publish it; until the tiles run out
+            extern __shared__ __attribute__((aligned(16))) float s_enc[];
+            const int nb = fu.enc_k >> 4, kq = lane >> 4, col = lane & 15;
+            const float *ebase = s_enc + lane;
+            for (;;) {
+                u32 t = 0;
                 if (lane == 0)
-                    old = atomicAdd(shard_head, (u32)kPage);
-                old = uniform(old);
-                page_pos = shard_base + old;
-                page_left = kPage;
-                if (old + (u32)kPage > shard_cap) {
-                    dead = true;
-                    if (lane == 0)
-                        atomicOr(&ctr->overflow, 2u);
-                }
-            }
-            if (!dead && !(dbg & 1)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { // exec = the quarter's ballot mask
-                    WPair e;
-                    e.w = w[q], e.pix = (u32)(q * 64 + lane);
-                    store_pair_masked(m[q], wpool + (page_pos + base[q] + mbcnt(m[q])), e);
-                }
-                if ((u32)lane < mid_pad + end_pad) { // {0, kPadPix} behind each half (kStore: behind the record): no remainder handling
-                    WPair z;
-                    z.w = 0.f, z.pix = kPadPix;
-                    wpool[page_pos + ((u32)lane < mid_pad ? base[2] - mid_pad + lane : total + lane - mid_pad)] = z;
-                }
-                // only the 256-channel scatter path wants the record's weight sum (its visit loop has no room for d), hence the
-                // template parameter
-                float wsum = 0.f; // the record's share of d[gid] (k_accum_d)
-                if constexpr (WSUM) {
-                    float wl = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        wl += mask_select(m[q], w[q], 0.f);
-                    wsum = wave_sum(wl);
-                }
+                    t = atomicAdd(fu.pc_queue, 1u);
+                t = uniform(t);
+                if (t >= (u32)n_tiles_all)
+                    break;
+                const int ptile = (int)tile_order[t];
+                const int ptx = ptile % V.tile_w, pty = ptile / V.tile_w;
+                u32 rs = 0;
                 if (lane == 0) {
-                    Header h;
-                    h.gid = (u32)__float_as_int(a.w);
-                    h.woff[0] = page_pos, h.woff[1] = page_pos + base[1];
-                    h.woff[2] = page_pos + base[2], h.woff[3] = page_pos + base[3];
-                    h.counts = cnt[0] | (cnt[1] << 8) | (cnt[2] << 16) | (cnt[3] << 24);
-                    // kHalves: a record with entries in BOTH halves of the tile gets the next carry row of its tile (k_scatter_wide
-                    // parks its partial sums there between the two half-tile passes): compact indices keep a workgroup's carry
-                    // rows few and hot in L2
-                    const bool spans = WSUM && (cnt[0] + cnt[1]) != 0 && (cnt[2] + cnt[3]) != 0;
-                    h.wsum = (u32)__float_as_int(wsum), h.carry_row = spans ? span_n : 0xFFFFFFFFu;
-                    h.mask[0] = m[0], h.mask[1] = m[1], h.mask[2] = m[2], h.mask[3] = m[3];
-                    headers[beg + hdr_n] = h;
-                    if constexpr (WSUM) { // gwbp_blend_weights_d: the record's share of d[gid] right here (no k_accum_d)
-                        if (d_out) // (spelled as the instruction: hipcc wraps a single-lane atomicAdd in its wave-aggregation code)
-                            asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(d_out + h.gid), "v"(wsum * scale_d) : "memory");
+                    for (;;) {
+                        bool got = false;
+                        for (u32 k = 0; k < (u32)kPcRing && !got; ++k)
+                            if (atomicCAS(&pc_state[k], kPcEmpty, kPcBusy) == kPcEmpty)
+                                rs = k, got = true;
+                        if (got)
+                            break;
+                        __builtin_amdgcn_s_sleep(8);
                     }
                 }
-                ++hdr_n;
-                if (WSUM && (cnt[0] + cnt[1]) != 0 && (cnt[2] + cnt[3]) != 0)
-                    ++span_n;
+                rs = uniform(rs);
+                float *dst = pc_ring + rs * kPcTileFloats;
+                const int cx = min(ptx * kTile + col, V.W - 1);
+                const u32 lane_off = (u32)(((int64_t)cx * fu.fs_x + 4 * kq) * (int64_t)sizeof(float));
+#pragma unroll 1
+                for (int q = 0; q < 4; ++q) {
+                    f32x4m R[4];
+                    encode_quarter<4>(fu.feats, fu.fs_y, V.H, pty, q, lane_off, nb, ebase, R); // 4 k-blocks in flight: 16 KB per wave
+                    // R[rho] of lane (col, g = kq) = outputs 4 g .. 4 g + 3 of pixel (col, row 4 q + rho): one 16-B store each; the
+                    // 16-B chunk index is xor-ed with the pixel's low bits so that neither these stores nor the consumers' reads of
+                    // four consecutive chunks per pixel pile onto the same LDS banks
+#pragma unroll
+                    for (int rho = 0; rho < 4; ++rho) {
+                        const int pix = (4 * q + rho) * 16 + col;
+                        *reinterpret_cast<f32x4m *>(dst + pix * kFusedCh + ((kq ^ (pix & 3)) << 2)) = R[rho];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the tile's stores before its publication
+                if (lane == 0)
+                    __hip_atomic_store(&pc_state[rs], (u32)ptile + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            page_pos += padded;
-            page_left -= padded;
-            npairs += total - mid_pad;
+            if (lane == 0)
+                atomicAdd(&pc_state[kPcRing], 1u); // (behind this wave's last publication: LDS operations of a wave complete in order)
+            return;
         }
     }
-    if (lane == 0) {
-        if ((FUSED || TOKEN) && slot == 0)
-            ctr->blend_kind = TOKEN ? kBlendToken : kBlendFused; // (no k_pool_stats launch behind these: the pool is untouched)
-        hdr_count[tile] = (FUSED || TOKEN) ? 0u : hdr_n; // kFused / kToken: the store stays empty
-        if (hdr_n)
-            atomicAdd(&ctr->n_headers, hdr_n);
-        if (npairs)
-            atomicAdd(&ctr->n_pairs, (u64)npairs);
-    }
-    if (alphas) {
+    u32 pc_slot = 0;
+    for (;;) { // (kFusedPC: a blend wave takes tile after tile from the ring; every other mode runs this body once)
+        int tile_sel;
+        if constexpr (PC) {
+            // ---- consumer wave: take any published ring slot; leave when every producer has finished and nothing is published
+            int got = -1;
+            if (lane == 0) {
+                for (;;) {
+                    for (u32 k = 0; k < (u32)kPcRing && got < 0; ++k) {
+                        const u32 v = __hip_atomic_load(&pc_state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (v >= 2u && atomicCAS(&pc_state[k], v, kPcBusy) == v)
+                            got = (int)((v - 2u) << 8 | k);
+                    }
+                    if (got >= 0)
+                        break;
+                    if (__hip_atomic_load(&pc_state[kPcRing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (u32)kPcProd) {
+                        // every producer has published its last tile: one more look at the ring, then leave
+                        for (u32 k = 0; k < (u32)kPcRing && got < 0; ++k) {
+                            const u32 v = __hip_atomic_load(&pc_state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (v >= 2u && atomicCAS(&pc_state[k], v, kPcBusy) == v)
+                                got = (int)((v - 2u) << 8 | k);
+                        }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            got = (int)uniform((u32)got);
+            if (got < 0)
+                return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            pc_slot = (u32)got & 0xFFu;
+            tile_sel = got >> 8;
+        } else {
+            if (WAVES > 1 && slot >= n_tiles_all)
+                return; // (behind the only barrier of the kernel: the waves of a workgroup are independent from here on)
+            tile_sel = (int)tile_order[slot]; // longest lists first
+        }
+        const int tile = tile_sel;
+        const int tx = tile % V.tile_w, ty = tile / V.tile_w;
+        const int ix = tx * kTile + (lane & 15), iy0 = ty * kTile + (lane >> 4);
+        const float px = (float)ix + 0.5f;
+        const u32 beg = tile_offsets[tile], end = tile_offsets[tile + 1];
+
+        // The weight pool is carved into kShards regions with their own head words: a single head saturates at
+        // ~88 returning same-address atomics per microsecond, which cost 1.0 ms/view with ~96 K page grabs per view.
+        const u32 shard = (u32)tile % (u32)kShards;
+        const u32 shard_cap = (pair_cap / (u32)kShards) & ~(u32)(kPage - 1);
+        const u32 shard_base = shard * shard_cap;
+        u32 *shard_head = shards + shard * 16;
+
+        // Per-pixel state.  T = 0 encodes "terminated or outside the image": a pixel with T = 0 can never produce a valid
+        // pair again (T (1 - alpha) = 0 <= 1e-4), so no separate done flag -- and none of the scalar mask bookkeeping a
+        // bool per lane costs (the first version of this loop issued more SALU than VALU instructions).  Tout keeps the
+        // transmittance to report (1 - Tout = alpha map), which the terminating Gaussian must not change.
+        float T[4], Tout[4], py[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int iy = iy0 + 4 * q;
-            if (ix < V.W && iy < V.H)
-                alphas[(size_t)iy * V.W + ix] = 1.0f - Tout[q];
+            py[q] = (float)iy + 0.5f;
+            T[q] = (ix < V.W && iy < V.H) ? 1.0f : 0.0f;
+            Tout[q] = 1.0f;
         }
-    }
+        u32 page_pos = 0, page_left = 0, npairs = 0, hdr_n = 0, span_n = 0; // wave-uniform
+        bool dead = false;                                     // wave-uniform: pool exhausted
+
+        // kToken: which of the tile's (at most) 2 x 2 tokens a pixel falls into, as lane masks: cmask = lanes whose column lies in the
+        // tile's SECOND token column, rmask[q] = lanes whose row 4 q + lane / 16 lies in its second token row.  The nearest index maps
+        // are non-decreasing; a tile that spans more than two token columns or rows (texels narrower than a tile) violates the entry
+        // point's precondition and raises overflow bit 3 -- the host never takes this path for such maps.
+        u64 cmask = 0ull, rmask[4] = {0ull, 0ull, 0ull, 0ull};
+        if constexpr (TOKEN) {
+            const int c_rel = fu.xmap[min(ix, V.W - 1)] - fu.xmap[min(tx * kTile, V.W - 1)];
+            cmask = __ballot(c_rel >= 1);
+            bool wide = c_rel > 1 || c_rel < 0;
+            const int r_base = fu.ymap[min(ty * kTile, V.H - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r_rel = fu.ymap[min(iy0 + 4 * q, V.H - 1)] - r_base;
+                rmask[q] = __ballot(r_rel >= 1);
+                wide |= r_rel > 1 || r_rel < 0;
+            }
+            if (__ballot(wide) != 0ull && lane == 0)
+                atomicOr(&ctr->overflow, kOverflowTokenGeometry);
+        }
+
+        // kFused: the lane's four pixels, kFusedCh channels each, stay in registers for the whole tile (pixels outside the
+        // image never get a weight: T = 0; they read a clamped address)
+        float f[FUSED ? 4 : 1][FUSED ? kFusedCh : 1];
+        if constexpr (MODE == kFusedEnc) {
+            // f[q][c] = sum_k feats[pixel (ix, iy0 + 4 q)][k] enc[k][c].  One MFMA tile = ONE TILE ROW: M = the 16 encoder outputs
+            // (A operand: lane (n = lane % 16, kq = lane / 16) reads its encoder value from LDS), N = the row's 16 pixels (B operand:
+            // lane (column = lane % 16, kq) holds the float4 feats[pixel][16 j + 4 kq ..] of k-block j, component i feeds step i),
+            // so the result registers of lane (column, g) are outputs 4 g .. 4 g + 3 of that row's pixel in ITS column.  Four
+            // rows (one quarter) are accumulated side by side -- the four encoder reads of a k-block serve 16 MFMAs -- and a
+            // 4 x 4 exchange between the lane rows hands every lane all 16 outputs of its own pixel (row 4 q + lane / 16).
+            extern __shared__ __attribute__((aligned(16))) float s_enc[];
+            const int kq = lane >> 4;
+            const int cx = min(ix, V.W - 1);
+            const int nb = fu.enc_k >> 4;
+            const float *ebase = s_enc + lane;
+            const u32 lane_off = (u32)(((int64_t)cx * fu.fs_x + 4 * kq) * (int64_t)sizeof(float));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4m R[4];
+                encode_quarter<2>(fu.feats, fu.fs_y, V.H, ty, q, lane_off, nb, ebase, R); // 2 k-blocks in flight: 8 KB per wave
+                // R[rho][r] of lane row g = output 4 g + r of the pixel (column, row 4 q + rho)  ->  f[q][4 g + r] of lane row rho
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x[4] = {R[0][r], R[1][r], R[2][r], R[3][r]};
+                    rows_transpose4(x);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        f[q][4 * g + r] = x[g];
+                }
+            }
+        }
+        if constexpr (PC) {
+            // the tile's encoded pixels from the ring slot into the registers the blend works from, then the slot is free again
+            const float *src = pc_ring + pc_slot * kPcTileFloats;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pix = (4 * q + (lane >> 4)) * 16 + (lane & 15);
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const f32x4m v = *reinterpret_cast<const f32x4m *>(src + pix * kFusedCh + ((c4 ^ (pix & 3)) << 2));
+                    f[q][4 * c4] = v[0], f[q][4 * c4 + 1] = v[1], f[q][4 * c4 + 2] = v[2], f[q][4 * c4 + 3] = v[3];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // (waits for the reads: the slot may be refilled behind it)
+            if (lane == 0)
+                __hip_atomic_store(&pc_state[pc_slot], kPcEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if constexpr (MODE == kFused) {
+            const int cx = min(ix, V.W - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float *src = fu.feats + (int64_t)min(iy0 + 4 * q, V.H - 1) * fu.fs_y + (int64_t)cx * fu.fs_x;
+                if (fu.vec4) {
+#pragma unroll
+                    for (int c4 = 0; c4 < kFusedCh / 4; ++c4) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (4 * c4 < fu.D)
+                            v = reinterpret_cast<const float4 *>(src)[c4];
+                        f[q][4 * c4] = v.x, f[q][4 * c4 + 1] = v.y, f[q][4 * c4 + 2] = v.z, f[q][4 * c4 + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < kFusedCh; ++c)
+                        f[q][c] = c < fu.D ? src[c] : 0.f;
+                }
+            }
+        }
+        // A non-finite feature value (backproject.py:109: feats / feats.norm() of an all-zero pixel is NaN) must reach exactly the
+        // Gaussians that have a weight AT that pixel -- the reference's backward adds fac * v_render for contributing pairs only.
+        // The record sums below multiply a lane's pixels by a weight that is 0 where the record has no entry, and 0 x NaN is NaN,
+        // which poisoned every record of the tile (found in round 5; the vector scatter kernels had been fixed in round 3).
+        // Once per tile: bad[q] = lanes whose pixel of quarter q holds a non-finite value (scalar masks), those pixels are zeroed
+        // in the registers, and a record whose entry mask meets bad[] gets NaN sums instead -- a few scalar instructions per
+        // record, no vector work in tiles without such pixels.  (All channels of the record become NaN, also where the reference
+        // would keep a finite or infinite one: the row is non-finite either way, and backproject.py:166-169 maps it to zeros.)
+        u64 bad[4] = {0ull, 0ull, 0ull, 0ull};
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float chk = 0.f;
+#pragma unroll
+                for (int c = 0; c < kFusedCh; ++c)
+                    chk = __builtin_fmaf(f[q][c], 0.f, chk); // NaN iff some value is NaN or +-inf
+                bad[q] = __ballot(chk != chk);
+                if (bad[q] != 0ull) { // (wave-uniform, rare)
+#pragma unroll
+                    for (int c = 0; c < kFusedCh; ++c)
+                        f[q][c] = (chk != chk) ? 0.f : f[q][c];
+                }
+            }
+        }
+        // per-lane constants of the record flush: lanes 0..15 add channel transposed_channel(lane) of F[gid], lane 16 adds d[gid]
+        const int my_ch = transposed_channel(lane);
+        float *out_base = nullptr;
+        size_t out_mul = 0;
+        float out_scale = 0.f;
+        bool out_on = false;
+        if constexpr (FUSED) {
+            out_base = lane < 16 ? fu.F + my_ch : d_out;
+            out_mul = lane < 16 ? (size_t)fu.D : (size_t)1;
+            out_scale = lane < 16 ? fu.scale_f : scale_d;
+            out_on = lane < 16 ? my_ch < fu.D : (lane == 16 && d_out != nullptr);
+        }
+
+        for (u32 batch = beg; batch < end; batch += kBatch) {
+            // quarters that still have a live pixel; stop when the whole tile has terminated (gsplat: all threads done)
+            u32 alive = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                alive |= (__ballot(T[q] > 0.f) != 0ull ? 1u : 0u) << q;
+            if (alive == 0)
+                break;
+            const u32 bn = min((u32)kBatch, end - batch);
+            if ((u32)lane < bn) {
+                const u32 gid = vals[batch + lane];
+                const float4 *gp = reinterpret_cast<const float4 *>(g2d + gid);
+                const float4 a = gp[0], b = gp[1];
+                // Conservative strip mask: bit q set <=> the Gaussian MAY reach alpha >= 1/255 somewhere in tile rows
+                // 4q..4q+3.  For a fixed dy the minimum of sigma over dx is dy^2 / (2 Syy) (Syy = ca / det(conic)), so a
+                // row with dy^2 > 2 Syy ln(255 o) cannot contribute; same in x for the whole tile.  Distances carry a
+                // 5 % + 1 px margin (>> fp32 error of sigma: conic entries are bounded by 1/eps2d), so a rejected
+                // (Gaussian, strip) provably has no contributing pixel and results are unchanged bit for bit.
+                u32 smask = 0;
+                const float L = __logf(255.0f * a.z); // ln(255 o); o <= 1/255 can never reach alpha >= 1/255
+                if (L > 0.f) {
+                    const float idet = 1.0f / (b.x * b.z - b.y * b.y);
+                    const float ex = 1.05f * __builtin_sqrtf(2.0f * L * b.z * idet) + 1.0f;
+                    const float ey = 1.05f * __builtin_sqrtf(2.0f * L * b.x * idet) + 1.0f;
+                    const float x0 = (float)(tx * kTile) + 0.5f, y0 = (float)(ty * kTile) + 0.5f;
+                    const bool xhit = !(a.x + ex < x0 || a.x - ex > x0 + 15.0f);
+                    if (xhit) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float ya = y0 + 4.0f * q;
+                            const bool miss = (a.y + ey < ya) || (a.y - ey > ya + 3.0f);
+                            smask |= (miss ? 0u : 1u) << q;
+                        }
+                    }
+                    if (!(ex == ex) || !(ey == ey))
+                        smask = 0xFu; // degenerate conic: never reject
+                }
+                s_a[lane] = make_float4(a.x, a.y, a.z, __int_as_float((int)gid));
+                s_b[lane] = make_float4(b.x, b.y, b.z, __int_as_float((int)smask));
+                // alpha = o exp(-sigma) >= 1/255  <=>  sigma <= ln(255 o); 1e-3 absorbs the error of __logf and exp_neg
+                s_thr[lane] = L + 1e-3f;
+                if constexpr (TOKEN) { // this (Gaussian, tile) pair's emit position: k_emit walked the rectangle row-major from estart
+                    const uint2 rc = fu.rect[gid];
+                    const u32 rx0 = rc.x & 0xFFFFu, rx1 = rc.x >> 16, ry0 = rc.y & 0xFFFFu;
+                    s_pos[lane] = fu.estart[gid] + ((u32)ty - ry0) * (rx1 - rx0) + ((u32)tx - rx0);
+                }
+            }
+            // single wave: LDS operations of one wave complete in program order, no barrier needed
+
+            for (u32 j = 0; j < bn && !(dbg & 2); ++j) {
+                const float4 b = s_b[j];
+                const u32 sm = uniform((u32)__float_as_int(b.w)) & alive;
+                if (sm == 0)
+                    continue; // this Gaussian cannot reach any live quarter of the tile
+                const float4 a = s_a[j];
+                const float thr = s_thr[j];
+                const float dx = a.x - px;
+                const float adx = b.x * dx, bdx = b.y * dx; // shared by the four quarters (same column)
+                u64 m[4];
+                float w[4];
+                // Per-lane control flow is branch-free and flag-free (float selects); the only branches are wave-uniform.
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    m[q] = 0ull, w[q] = 0.f;
+                    if ((sm >> q) & 1u) {
+                        const float dy = a.y - py[q];
+                        const float sigma = __builtin_fmaf(bdx, dy, 0.5f * __builtin_fmaf(adx, dx, (b.z * dy) * dy));
+                        // no live pixel of this quarter lies inside the alpha >= 1/255 ellipse: skip exp / T / ballot
+                        if (__ballot(T[q] > 0.f && sigma <= thr) == 0ull)
+                            continue;
+                        const float alpha = __builtin_fminf(kAlphaMax, a.z * exp_neg_sigma(sigma));
+                        // The three tests as lane masks (a ballot of a COMPARE is that compare's own SGPR result; a ballot of
+                        // their conjunction costs v_cndmask + v_cmp_ne), combined on the scalar unit.
+                        const float next_T = T[q] * (1.0f - alpha);
+                        const u64 m_ok = __builtin_amdgcn_ballot_w64(sigma >= 0.f) &       // sigma < 0: skipped
+                                         __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin);  // alpha < 1/255: skipped
+                        const u64 m_valid = m_ok & __builtin_amdgcn_ballot_w64(next_T > kTMin); // T' <= 1e-4: terminates, NOT counted
+                        const float T_else = mask_select(m_ok, 0.f, T[q]);       // ok but not valid -> terminated
+                        w[q] = alpha * T[q];
+                        T[q] = mask_select(m_valid, next_T, T_else);
+                        Tout[q] = mask_select(m_valid, next_T, Tout[q]);
+                        m[q] = m_valid;
+                    }
+                }
+                if ((m[0] | m[1] | m[2] | m[3]) == 0ull) {
+                    // a quarter may have died without contributing: refresh the live set lazily
+                    if ((j & 7u) == 7u) {
+                        alive = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            alive |= (__ballot(T[q] > 0.f) != 0ull ? 1u : 0u) << q;
+                        if (alive == 0)
+                            break;
+                    }
+                    continue;
+                }
+                // Entry layout of a record: quarters 0 | 1 back to back, then quarters 2 | 3 back to back.  kHalves: the second half
+                // starts on a multiple of kListPad entries (64 B), i.e. BOTH half-tile lists are padded -- k_scatter_wide fetches a
+                // half's entries eight at a time with s_load_dwordx16 and must find {0, kPadPix} behind the last real one.
+                u32 cnt[4], base[4], total = 0, mid_pad = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    cnt[q] = (u32)__popcll(m[q]);
+                    if (WSUM && q == 2) {
+                        mid_pad = (0u - total) & (u32)(kListPad - 1);
+                        total += mid_pad;
+                    }
+                    base[q] = total;
+                    total += cnt[q];
+                }
+                if constexpr (TOKEN) {
+                    // the record's four token-quadrant weight sums (index qx | qy << 1), one 16-B line at its emit position
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (m[q] != 0ull) { // wave-uniform
+                            const float wq = mask_select(m[q], w[q], 0.f);
+                            a1 += mask_select(rmask[q], wq, 0.f);
+                            a0 += mask_select(rmask[q], 0.f, wq);
+                        }
+                    const float r = transposed_sum4(mask_select(cmask, 0.f, a0), mask_select(cmask, a0, 0.f),
+                                                    mask_select(cmask, 0.f, a1), mask_select(cmask, a1, 0.f));
+                    if (!(dbg & 1) && lane < 4)
+                        fu.omega[(size_t)s_pos[j] * 4 + lane] = r;
+                    ++hdr_n;
+                    npairs += total;
+                    continue;
+                }
+                if constexpr (FUSED) {
+                    float p[kFusedCh], wl = 0.f;
+#pragma unroll
+                    for (int c = 0; c < kFusedCh; ++c)
+                        p[c] = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (m[q] != 0ull) { // wave-uniform
+                            const float wq = mask_select(m[q], w[q], 0.f); // the ballot register is the select mask
+                            wl += wq;
+#pragma unroll
+                            for (int c = 0; c < kFusedCh; ++c)
+                                p[c] = __builtin_fmaf(wq, f[q][c], p[c]);
+                        }
+                    float tot = transposed_sum16(p); // every row: channel my_ch
+                    if (((m[0] & bad[0]) | (m[1] & bad[1]) | (m[2] & bad[2]) | (m[3] & bad[3])) != 0ull) // (scalar; see bad[] above)
+                        tot = __builtin_nanf("");
+                    wl += dpp_get<0xB1>(wl);
+                    wl += dpp_get<0x4E>(wl);
+                    wl += dpp_get<0x141>(wl);
+                    wl += dpp_get<0x140>(wl);
+                    const float ws = rows_sum(wl);
+                    if (!(dbg & 1) && out_on) {
+                        // one atomic instruction: lanes 0..15 the record's channel sums, lane 16 its share of d
+                        const u32 gid = (u32)__float_as_int(a.w);
+                        atomicAdd(out_base + (size_t)gid * out_mul, (lane < 16 ? tot : ws) * out_scale);
+                    }
+                    ++hdr_n;
+                    npairs += total;
+                    continue;
+                }
+                const u32 padded = (total + (kListPad - 1)) & ~(u32)(kListPad - 1);
+                const u32 end_pad = padded - total;
+                if (padded > page_left) {
+                    u32 old = 0;
+                    if (lane == 0)
+                        old = atomicAdd(shard_head, (u32)kPage);
+                    old = uniform(old);
+                    page_pos = shard_base + old;
+                    page_left = kPage;
+                    if (old + (u32)kPage > shard_cap) {
+                        dead = true;
+                        if (lane == 0)
+                            atomicOr(&ctr->overflow, 2u);
+                    }
+                }
+                if (!dead && !(dbg & 1)) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { // exec = the quarter's ballot mask
+                        WPair e;
+                        e.w = w[q], e.pix = (u32)(q * 64 + lane);
+                        store_pair_masked(m[q], wpool + (page_pos + base[q] + mbcnt(m[q])), e);
+                    }
+                    if ((u32)lane < mid_pad + end_pad) { // {0, kPadPix} behind each half (kStore: behind the record): no remainder handling
+                        WPair z;
+                        z.w = 0.f, z.pix = kPadPix;
+                        wpool[page_pos + ((u32)lane < mid_pad ? base[2] - mid_pad + lane : total + lane - mid_pad)] = z;
+                    }
+                    // only the 256-channel scatter path wants the record's weight sum (its visit loop has no room for d), hence the
+                    // template parameter
+                    float wsum = 0.f; // the record's share of d[gid] (k_accum_d)
+                    if constexpr (WSUM) {
+                        float wl = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            wl += mask_select(m[q], w[q], 0.f);
+                        wsum = wave_sum(wl);
+                    }
+                    if (lane == 0) {
+                        Header h;
+                        h.gid = (u32)__float_as_int(a.w);
+                        h.woff[0] = page_pos, h.woff[1] = page_pos + base[1];
+                        h.woff[2] = page_pos + base[2], h.woff[3] = page_pos + base[3];
+                        h.counts = cnt[0] | (cnt[1] << 8) | (cnt[2] << 16) | (cnt[3] << 24);
+                        // kHalves: a record with entries in BOTH halves of the tile gets the next carry row of its tile (k_scatter_wide
+                        // parks its partial sums there between the two half-tile passes): compact indices keep a workgroup's carry
+                        // rows few and hot in L2
+                        const bool spans = WSUM && (cnt[0] + cnt[1]) != 0 && (cnt[2] + cnt[3]) != 0;
+                        h.wsum = (u32)__float_as_int(wsum), h.carry_row = spans ? span_n : 0xFFFFFFFFu;
+                        h.mask[0] = m[0], h.mask[1] = m[1], h.mask[2] = m[2], h.mask[3] = m[3];
+                        headers[beg + hdr_n] = h;
+                        if constexpr (WSUM) { // gwbp_blend_weights_d: the record's share of d[gid] right here (no k_accum_d)
+                            if (d_out) // (spelled as the instruction: hipcc wraps a single-lane atomicAdd in its wave-aggregation code)
+                                asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(d_out + h.gid), "v"(wsum * scale_d) : "memory");
+                        }
+                    }
+                    ++hdr_n;
+                    if (WSUM && (cnt[0] + cnt[1]) != 0 && (cnt[2] + cnt[3]) != 0)
+                        ++span_n;
+                }
+                page_pos += padded;
+                page_left -= padded;
+                npairs += total - mid_pad;
+            }
+        }
+        if (lane == 0) {
+            if ((FUSED || TOKEN) && (PC ? (blockIdx.x == 0 && wave == kPcProd) : slot == 0))
+                ctr->blend_kind = TOKEN ? kBlendToken : kBlendFused; // (no k_pool_stats launch behind these: the pool is untouched)
+            hdr_count[tile] = (FUSED || TOKEN) ? 0u : hdr_n; // kFused / kToken: the store stays empty
+            if (hdr_n)
+                atomicAdd(&ctr->n_headers, hdr_n);
+            if (npairs)
+                atomicAdd(&ctr->n_pairs, (u64)npairs);
+        }
+        if (alphas) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int iy = iy0 + 4 * q;
+                if (ix < V.W && iy < V.H)
+                    alphas[(size_t)iy * V.W + ix] = 1.0f - Tout[q];
+            }
+        }
+        if constexpr (!PC)
+            break;
+    } // for (;;): the next tile of a kFusedPC blend wave
 }
 
 // Small images (<= kQuarterMaxTiles tiles): the fused blend + scatter with ONE QUARTER of a tile per wave, lane = one pixel.
@@ -944,7 +1093,20 @@ int launch_blend(const Layout &L, const Ws &W, const ViewDev &V, float *alphas, 
     hipLaunchKernelGGL(k_blend<H>, dim3(n_tiles), dim3(64), (size_t)extra_lds, s, V, W.tile_offsets, W.vals[fin], W.g2d,  \
                        W.counters, W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, W.tile_order, alphas,  \
                        ablate, prio, d, scale_d, fu)
-    if (fused_enc) {
+    if (fused_enc && (L.flags & GWBP_FLAG_SPLIT_ENCODER)) {
+        // producer / consumer form: ONE persistent workgroup per CU (kPcProd encoder waves + blend waves around a ring of encoded
+        // tiles in LDS); the tile counter is the first scatter queue word, which gwbp_project's memset left zero
+        const size_t lds = (size_t)fu.enc_k * kFusedCh * sizeof(float) + (size_t)kPcRing * kPcTileFloats * sizeof(float) + 64;
+        int n_cu = 0;
+        int rc = device_cus(&n_cu);
+        if (rc || (rc = ensure_dynamic_lds(reinterpret_cast<const void *>(k_blend<kFusedPC, kPcWaves>),
+                                           kEncMaxK * kFusedCh * 4 + kPcRing * kPcTileFloats * 4 + 64, 14)))
+            return rc;
+        fu.pc_queue = W.shards + kShards * 16;
+        hipLaunchKernelGGL((k_blend<kFusedPC, kPcWaves>), dim3(n_cu), dim3(64 * kPcWaves), lds, s, V, W.tile_offsets, W.vals[fin],
+                           W.g2d, W.counters, W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap, W.shards, W.tile_order, alphas,
+                           ablate, prio, d, scale_d, fu);
+    } else if (fused_enc) {
         const size_t lds = (size_t)fu.enc_k * kFusedCh * sizeof(float);
         hipLaunchKernelGGL((k_blend<kFusedEnc, kEncWaves>), dim3((n_tiles + kEncWaves - 1) / kEncWaves), dim3(64 * kEncWaves), lds, s,
                            V, W.tile_offsets, W.vals[fin], W.g2d, W.counters, W.headers, W.hdr_count, W.wpool, (u32)L.pair_cap,

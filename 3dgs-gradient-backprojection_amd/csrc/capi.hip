@@ -95,7 +95,7 @@ int make_layout(const gwbp_caps *c, Layout *L)
         return set_error(GWBP_EINVAL, "caps out of range (N=%lld isect_cap=%lld pair_cap=%lld %dx%d)",
                          (long long)c->n_gaussians, (long long)c->isect_cap, (long long)c->pair_cap, c->max_width,
                          c->max_height);
-    if (c->flags & ~(GWBP_FLAG_TIGHT_BINNING | GWBP_FLAG_FRONT_PRIORITY | GWBP_FLAG_NARROW_SCATTER))
+    if (c->flags & ~(GWBP_FLAG_TIGHT_BINNING | GWBP_FLAG_FRONT_PRIORITY | GWBP_FLAG_NARROW_SCATTER | GWBP_FLAG_SPLIT_ENCODER))
         return set_error(GWBP_EINVAL, "unknown caps.flags bits 0x%x", (unsigned)c->flags);
     memset(L, 0, sizeof(*L));
     L->n = c->n_gaussians;

@@ -85,6 +85,14 @@ class Engine:
         else:
             self.caps.flags &= ~_lib.FLAG_FRONT_PRIORITY
 
+    def set_split_encoder(self, on: bool) -> None:
+        """GWBP_FLAG_SPLIT_ENCODER: blend_scatter_encoded as ONE persistent launch of encoder (producer) waves and blend (consumer)
+        waves around an LDS ring of encoded tiles (the compressed variant on large images, see gwbp.h)."""
+        if on:
+            self.caps.flags |= _lib.FLAG_SPLIT_ENCODER
+        else:
+            self.caps.flags &= ~_lib.FLAG_SPLIT_ENCODER
+
     def set_narrow_scatter(self, on: bool) -> None:
         """GWBP_FLAG_NARROW_SCATTER: the 128-channel scatter kernel even when D % 256 == 0 (short records, see gwbp.h).
         An Engine starts narrow (k_blend then skips the half-tile lists only the 256-channel kernel reads); whoever
@@ -97,7 +105,7 @@ class Engine:
 
     def _alloc(self):
         # run-time flags survive a re-allocation (grow); a new engine starts narrow
-        run = (self.caps.flags & (_lib.FLAG_FRONT_PRIORITY | _lib.FLAG_NARROW_SCATTER)
+        run = (self.caps.flags & (_lib.FLAG_FRONT_PRIORITY | _lib.FLAG_NARROW_SCATTER | _lib.FLAG_SPLIT_ENCODER)
                if hasattr(self, "caps") else _lib.FLAG_NARROW_SCATTER)
         base = _lib.FLAG_TIGHT_BINNING if self.tight_binning else 0
         self.caps = Caps(self.n, self.isect_cap, self.pair_cap, self.max_w, self.max_h, self.scatter_workgroups, base | run)

@@ -64,9 +64,11 @@ def main():
     ap.add_argument("--side-prio", type=int, default=-1, help="HIP priority of the front stage's stream")
     ap.add_argument("--front-prio", choices=("auto", "on", "off"), default="auto",
                     help="raised wave priority for the front-stage kernels (auto: with the 256-channel scatter kernel)")
-    ap.add_argument("--encoder", choices=("fused", "ahead", "blend"), default="blend",
+    ap.add_argument("--encoder", choices=("fused", "ahead", "blend", "split"), default="blend",
                     help="C5: encoder inside the small-D scatter kernel's slab staging (fused), a separate kernel one view ahead "
-                         "(ahead), or inside the fused blend + scatter kernel's tile prologue (blend: gwbp_blend_scatter_encoded)")
+                         "(ahead), inside the fused blend + scatter kernel's tile prologue (blend: gwbp_blend_scatter_encoded), or "
+                         "that kernel's producer / consumer form (split: GWBP_FLAG_SPLIT_ENCODER -- encoder waves and blend waves "
+                         "of one persistent launch around an LDS ring of encoded tiles)")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for the one-GPU check)")
     ap.add_argument("--one-device", action="store_true",
                     help="every rank uses cuda:0 (checks the N > 1 bookkeeping on a one-GPU box together with --dist-backend gloo)")
@@ -84,6 +86,7 @@ def main():
     ap.add_argument("--token-space", choices=("on", "off"), default="on",
                     help="DINO64: nearest-upsampled maps whose texels cover a tile go through token space (gwbp_blend_tokens + "
                          "gwbp_scatter_tokens: no atomics); off = the pixel-slab kernels with index maps (gwbp_scatter_upsampled)")
+    ap.add_argument("--split-depth", type=int, default=0, help="--encoder split: views in flight (0 = the driver's choice)")
     ap.add_argument("--no-fuse-small", action="store_true",
                     help="D <= 16: keep blend (weight store) and scatter as two kernels instead of gwbp_blend_scatter")
     ap.add_argument("--total-views", type=int, default=0,
@@ -194,8 +197,14 @@ def main():
     allow_wide = args.scatter != "narrow"
     if args.serial:
         eng.set_narrow_scatter(not (D % 256 == 0 and allow_wide))
+        if encoder is not None and args.encoder == "split":
+            eng.set_split_encoder(True)
+            args.encoder = "blend"
         pipe, accum = None, torch.zeros(32, dtype=torch.uint8, device=dev)
     else:
+        split = encoder is not None and args.encoder == "split"
+        if split:
+            args.encoder = "blend"  # (the same entry point and schedule; the engines carry GWBP_FLAG_SPLIT_ENCODER)
         enc_blend = encoder is not None and args.encoder == "blend" and not args.no_fuse_small
         depth = args.depth or gsbp_amd.backproject.pipeline_depth(N, W, H, D, encoder_in_blend=enc_blend)
         more = [gsbp_amd.Engine(N, W, H, device=dev, isect_cap=eng.isect_cap, pair_cap=eng.pair_cap, tight_binning=tight)
@@ -205,7 +214,7 @@ def main():
                                      front_priority=None if args.front_prio == "auto" else args.front_prio == "on",
                                      fuse_small=not args.no_fuse_small, side_streams=args.side_streams,
                                      view_per_stream=True if (args.view_per_stream or (enc_blend and depth > 2)) else None,
-                                     token_grid=token_grid)
+                                     token_grid=token_grid, split_encoder=split)
         accum = pipe.accum
         if args.enc_wgs_per_cu:
             pipe.ENCODER_WORKGROUPS_PER_CU = args.enc_wgs_per_cu
@@ -406,8 +415,12 @@ def main():
         # PMC counters cannot be collected from inside this process: `traffic` is the HBM byte count per launch of the
         # SAME kernel and workload from the committed rocprofv3 --pmc passes (tools/profile_round.sh, separate runs)
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        split_on = bool(eng.caps.flags & gsbp_amd._lib.FLAG_SPLIT_ENCODER)
         scatter_kernel = ("k_token_apply (token space: per-record token-quadrant weight sums from k_blend<kToken>, one plain "
                           "read-modify-write per F row, no atomics)" if token_grid is not None else
+                          "k_blend<kFusedPC> (encoder waves + blend/scatter waves of one persistent launch around an LDS ring of "
+                          "encoded tiles, no encoded map, no weight store)"
+                          if fused_small and encoder is not None and args.encoder == "blend" and split_on else
                           "k_blend<kFusedEnc> (encoder + blend + scatter in one kernel, no encoded map, no weight store)"
                           if fused_small and encoder is not None and args.encoder == "blend" else
                           ("k_blend_scatter_quarter" if gsbp_amd.Engine.fused_max_dim(W, H) > gsbp_amd.Engine.FUSED_MAX_DIM

@@ -222,9 +222,11 @@ def test_c4_full_size_invariants_and_oracle_subset(dev, orc, monkeypatch):
     assert np.abs(out[sel_t].cpu().numpy() - orc.finalize(Fr, dr)).max() <= 1e-4
 
 
-def test_c5_full_size_encoder_path_against_oracle(dev, orc):
+@pytest.mark.parametrize("split", [True, False], ids=["producer_consumer", "one_wave_per_tile"])
+def test_c5_full_size_encoder_path_against_oracle(dev, orc, split):
     """BASELINE.json configs[4] (backproject_compressed.py:127-165): 1M Gaussians, 512 -> 16 encoder, two full-size
-    views through the pipelined driver; the oracle gets the map encoded on the CPU."""
+    views through the pipelined driver; the oracle gets the map encoded on the CPU.  The fused kernel in both forms: encoder
+    waves + blend waves of one persistent launch (round 6, GWBP_FLAG_SPLIT_ENCODER) and one wave per tile (round 5)."""
     cfg = syn.CONFIGS["C5"]
     V = 2
     g_cpu = syn.activate(syn.make_scene(cfg))
@@ -233,7 +235,7 @@ def test_c5_full_size_encoder_path_against_oracle(dev, orc):
     enc = syn.make_encoder(cfg)
     maps = [syn.make_feature_map(cfg, 40 + v, device=dev) for v in range(V)]
     out, F, d, st = gsbp_amd.create_feature_field(*g, vms.to(dev), K.to(dev), cfg.width, cfg.height, lambda v: maps[v],
-                                                  cfg.feat_dim, encoder=enc.to(dev), return_partials=True)
+                                                  cfg.feat_dim, encoder=enc.to(dev), return_partials=True, encoder_split=split)
     assert st["overflow"] == 0 and tuple(F.shape) == (cfg.n_gaussians, cfg.encoder_dim)
     # the same job with the encoder fused into the scatter kernel's slab staging (gwbp_scatter_encoded)
     _, F2, d2, st2 = gsbp_amd.create_feature_field(*g, vms.to(dev), K.to(dev), cfg.width, cfg.height, lambda v: maps[v],

@@ -1000,8 +1000,9 @@ def test_scatter_encoded_matches_scatter_of_encoded_map(orc, dev, K, n):
     assert rel_row_err(res[0][1].cpu().numpy()[:, None], dr[:, None]) <= TOL
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["one_wave_per_tile", "producer_consumer"])
 @pytest.mark.parametrize("name,K,n", [("T1", 512, 16), ("T1", 64, 5), ("T0", 32, 16), ("C1", 128, 16)])
-def test_blend_scatter_encoded_matches_encode_then_blend_scatter(orc, dev, name, K, n):
+def test_blend_scatter_encoded_matches_encode_then_blend_scatter(orc, dev, name, K, n, split):
     """gwbp_blend_scatter_encoded (round 5: the 512 -> 16 encoder of backproject_compressed.py:127 inside the fused blend +
     scatter kernel's tile prologue, on the matrix cores) against gwbp_encode_map + gwbp_blend_scatter of the same view -- the
     encoded pixels are the same k-ordered fp32 chain, so the weights are equal and F, d differ by summation order only -- and
@@ -1014,6 +1015,9 @@ def test_blend_scatter_encoded_matches_encode_then_blend_scatter(orc, dev, name,
     enc = torch.randn(K, n, generator=g) / K ** 0.5
     N = cfg.n_gaussians
     eng = gsbp_amd.Engine(N, cfg.width, cfg.height, device=dev)
+    # round 6: the same entry point in its producer / consumer form (GWBP_FLAG_SPLIT_ENCODER: encoder waves fill an LDS ring of
+    # encoded tiles, blend waves drain it, one persistent workgroup per CU) -- same encoded pixels, same weights
+    eng.set_split_encoder(split)
     view = eng.view(d["vms"][0], d["K"], cfg.width, cfg.height)
 
     def front():
@@ -1131,7 +1135,7 @@ def test_dropin_denominator_pass_from_the_weight_sums(orc, dev):
     assert rel_row_err(got[:, :1].cpu().numpy() / 2.5, dr[:, None]) <= TOL
 
 
-def _nonfinite_case(orc, dev, name, D, fused, enc_k=None):
+def _nonfinite_case(orc, dev, name, D, fused, enc_k=None, split=False):
     """One view, a feature map with a NaN pixel and a +inf pixel: NaN must reach exactly the Gaussians that have a weight at one
     of those pixels (the reference's backward adds fac * v_render only for contributing pairs), every other row must match the
     oracle.  backproject.py:109 produces such pixels: feats / feats.norm() of an all-zero pixel."""
@@ -1150,6 +1154,7 @@ def _nonfinite_case(orc, dev, name, D, fused, enc_k=None):
     bad_ref = ~np.isfinite(Fr).all(axis=1)
     assert 0 < bad_ref.sum() < N // 2
     eng = gsbp_amd.Engine(N, W, H, device=dev)
+    eng.set_split_encoder(split)
     view = eng.view(d["vms"][0], d["K"], W, H)
     eng.project(view, d["means"], d["quats"], d["scales"], d["opac"])
     eng.bin_sort(view)
@@ -1168,13 +1173,14 @@ def _nonfinite_case(orc, dev, name, D, fused, enc_k=None):
     assert rel_row_err(dd.cpu().numpy()[:, None], dr[:, None]) <= TOL
 
 
-@pytest.mark.parametrize("name,D,fused,enc_k", [("T1", 8, False, None), ("T1", 130, False, None), ("T1", 128, False, None),
-                                                ("T1", 256, False, None), ("T1", 16, True, None), ("T1", 5, True, None),
-                                                ("C1", 32, True, None), ("T1", 16, False, 64)],
+@pytest.mark.parametrize("name,D,fused,enc_k,split",
+                         [("T1", 8, False, None, False), ("T1", 130, False, None, False), ("T1", 128, False, None, False),
+                          ("T1", 256, False, None, False), ("T1", 16, True, None, False), ("T1", 5, True, None, False),
+                          ("C1", 32, True, None, False), ("T1", 16, False, 64, False), ("T1", 16, False, 64, True)],
                          ids=["small_D8", "general_D130", "narrow_D128", "wide_D256", "fused_D16", "fused_D5", "fused_quarter_D32",
-                              "fused_encoder_64to16"])
-def test_non_finite_features_reach_exactly_the_gaussians_that_touch_them(orc, dev, name, D, fused, enc_k):
-    _nonfinite_case(orc, dev, name, D, fused, enc_k)
+                              "fused_encoder_64to16", "fused_encoder_64to16_producer_consumer"])
+def test_non_finite_features_reach_exactly_the_gaussians_that_touch_them(orc, dev, name, D, fused, enc_k, split):
+    _nonfinite_case(orc, dev, name, D, fused, enc_k, split)
 
 
 def test_profile_build_of_the_wide_kernel_agrees_with_the_narrow_one(dev):
