@@ -66,6 +66,8 @@ constexpr int kPcRing = 6;      // ... filling a ring of this many encoded tiles
 constexpr int kPcTileFloats = kTilePix * kFusedCh;
 // ring slot states: 0 = empty, 1 = claimed (being filled or being read), tile + 2 = holds that tile's encoded pixels
 constexpr u32 kPcEmpty = 0u, kPcBusy = 1u;
+constexpr u32 kPcStalled = 0xFFu;       // "no slot": a wait on the ring gave up
+constexpr u32 kPcMaxSpins = 1u << 22;   // s_sleep(8) polls (~0.25 us each) before a ring wait gives up: about a second
 
 struct FusedArgs { // kFused only
     const float *feats; // feats[y * fs_y + x * fs_x + c], c < D
@@ -344,6 +346,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             pc_state = reinterpret_cast<u32 *>(pc_ring + kPcRing * kPcTileFloats);
             if (threadIdx.x <= kPcRing)
                 pc_state[threadIdx.x] = 0u; // kPcRing slot states + the finished-producers count
+            if (blockIdx.x == 0 && threadIdx.x == 0)
+                ctr->blend_kind = kBlendFused; // (no k_pool_stats launch behind the fused kernels: the pool is untouched)
         }
         __syncthreads();
     }
@@ -354,47 +358,60 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             extern __shared__ __attribute__((aligned(16))) float s_enc[];
             const int nb = fu.enc_k >> 4, kq = lane >> 4, col = lane & 15;
             const float *ebase = s_enc + lane;
-            for (;;) {
+            // (Control flow of this loop is kept to plain if / else with wave-uniform conditions, every LDS atomic alone under
+            // `lane == 0`, the publication stored by all lanes -- no `break` out of the tile loop, no one-lane branch behind the
+            // encode: with those, hipcc's control-flow structuriser built a loop that lane 0 left and lanes 1..63 went round
+            // again, and the first version of this kernel hung the device.)
+            bool more = true;
+            while (more) {
                 u32 t = 0;
                 if (lane == 0)
                     t = atomicAdd(fu.pc_queue, 1u);
                 t = uniform(t);
-                if (t >= (u32)n_tiles_all)
-                    break;
-                const int ptile = (int)tile_order[t];
-                const int ptx = ptile % V.tile_w, pty = ptile / V.tile_w;
-                u32 rs = 0;
-                if (lane == 0) {
-                    for (;;) {
-                        bool got = false;
-                        for (u32 k = 0; k < (u32)kPcRing && !got; ++k)
-                            if (atomicCAS(&pc_state[k], kPcEmpty, kPcBusy) == kPcEmpty)
-                                rs = k, got = true;
-                        if (got)
-                            break;
-                        __builtin_amdgcn_s_sleep(8);
+                if (t < (u32)n_tiles_all) {
+                    const int ptile = (int)tile_order[t];
+                    const int ptx = ptile % V.tile_w, pty = ptile / V.tile_w;
+                    u32 rs = kPcStalled;
+                    for (u32 spins = 0; spins < kPcMaxSpins && rs == kPcStalled; ++spins) {
+                        for (u32 k = 0; k < (u32)kPcRing && rs == kPcStalled; ++k) {
+                            u32 old = kPcBusy;
+                            if (lane == 0)
+                                old = atomicCAS(&pc_state[k], kPcEmpty, kPcBusy);
+                            if (uniform(old) == kPcEmpty)
+                                rs = k;
+                        }
+                        if (rs == kPcStalled)
+                            __builtin_amdgcn_s_sleep(8);
                     }
-                }
-                rs = uniform(rs);
-                float *dst = pc_ring + rs * kPcTileFloats;
-                const int cx = min(ptx * kTile + col, V.W - 1);
-                const u32 lane_off = (u32)(((int64_t)cx * fu.fs_x + 4 * kq) * (int64_t)sizeof(float));
+                    if (rs != kPcStalled) {
+                        float *dst = pc_ring + rs * kPcTileFloats;
+                        const int cx = min(ptx * kTile + col, V.W - 1);
+                        const u32 lane_off = (u32)(((int64_t)cx * fu.fs_x + 4 * kq) * (int64_t)sizeof(float));
 #pragma unroll 1
-                for (int q = 0; q < 4; ++q) {
-                    f32x4m R[4];
-                    encode_quarter<4>(fu.feats, fu.fs_y, V.H, pty, q, lane_off, nb, ebase, R); // 4 k-blocks in flight: 16 KB per wave
-                    // R[rho] of lane (col, g = kq) = outputs 4 g .. 4 g + 3 of pixel (col, row 4 q + rho): one 16-B store each; the
-                    // 16-B chunk index is xor-ed with the pixel's low bits so that neither these stores nor the consumers' reads of
-                    // four consecutive chunks per pixel pile onto the same LDS banks
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4m R[4];
+                            encode_quarter<4>(fu.feats, fu.fs_y, V.H, pty, q, lane_off, nb, ebase, R); // 4 k-blocks in flight: 16 KB per wave
+                            // R[rho] of lane (col, g = kq) = outputs 4 g .. 4 g + 3 of pixel (col, row 4 q + rho): one 16-B store each;
+                            // the 16-B chunk index is xor-ed with the pixel's low bits so that neither these stores nor the consumers'
+                            // reads of four consecutive chunks per pixel pile onto the same LDS banks
 #pragma unroll
-                    for (int rho = 0; rho < 4; ++rho) {
-                        const int pix = (4 * q + rho) * 16 + col;
-                        *reinterpret_cast<f32x4m *>(dst + pix * kFusedCh + ((kq ^ (pix & 3)) << 2)) = R[rho];
+                            for (int rho = 0; rho < 4; ++rho) {
+                                const int pix = (4 * q + rho) * 16 + col;
+                                *reinterpret_cast<f32x4m *>(dst + pix * kFusedCh + ((kq ^ (pix & 3)) << 2)) = R[rho];
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the tile's stores before its publication
+                        __hip_atomic_store(&pc_state[rs], (u32)ptile + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        // (never seen: the blend waves free a slot as soon as they have copied it.  A protocol error must end the
+                        // launch with a flag, not hang the device)
+                        if (lane == 0)
+                            atomicOr(&ctr->overflow, kOverflowRingStall);
+                        more = false;
                     }
+                } else {
+                    more = false;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the tile's stores before its publication
-                if (lane == 0)
-                    __hip_atomic_store(&pc_state[rs], (u32)ptile + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (lane == 0)
                 atomicAdd(&pc_state[kPcRing], 1u); // (behind this wave's last publication: LDS operations of a wave complete in order)
@@ -407,28 +424,40 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
         if constexpr (PC) {
             // ---- consumer wave: take any published ring slot; leave when every producer has finished and nothing is published
             int got = -1;
-            if (lane == 0) {
-                for (;;) {
+            {
+                // one look at the ring (wave-uniform loop, the atomics under `lane == 0`: see the producers' note)
+                auto scan = [&]() __attribute__((always_inline)) {
                     for (u32 k = 0; k < (u32)kPcRing && got < 0; ++k) {
-                        const u32 v = __hip_atomic_load(&pc_state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (v >= 2u && atomicCAS(&pc_state[k], v, kPcBusy) == v)
+                        u32 v = 0, old = ~0u;
+                        if (lane == 0) {
+                            v = __hip_atomic_load(&pc_state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (v >= 2u)
+                                old = atomicCAS(&pc_state[k], v, kPcBusy);
+                        }
+                        v = uniform(v), old = uniform(old);
+                        if (v >= 2u && old == v)
                             got = (int)((v - 2u) << 8 | k);
                     }
+                };
+                for (u32 spins = 0; got < 0; ++spins) {
+                    if (spins >= kPcMaxSpins) { // (see the producers' guard)
+                        if (lane == 0)
+                            atomicOr(&ctr->overflow, kOverflowRingStall);
+                        break;
+                    }
+                    scan();
                     if (got >= 0)
                         break;
-                    if (__hip_atomic_load(&pc_state[kPcRing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (u32)kPcProd) {
-                        // every producer has published its last tile: one more look at the ring, then leave
-                        for (u32 k = 0; k < (u32)kPcRing && got < 0; ++k) {
-                            const u32 v = __hip_atomic_load(&pc_state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (v >= 2u && atomicCAS(&pc_state[k], v, kPcBusy) == v)
-                                got = (int)((v - 2u) << 8 | k);
-                        }
+                    u32 fin = 0;
+                    if (lane == 0)
+                        fin = __hip_atomic_load(&pc_state[kPcRing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (uniform(fin) == (u32)kPcProd) {
+                        scan(); // every producer has published its last tile: one more look at the ring, then leave
                         break;
                     }
                     __builtin_amdgcn_s_sleep(8);
                 }
             }
-            got = (int)uniform((u32)got);
             if (got < 0)
                 return;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -531,8 +560,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // (waits for the reads: the slot may be refilled behind it)
-            if (lane == 0)
-                __hip_atomic_store(&pc_state[pc_slot], kPcEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&pc_state[pc_slot], kPcEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (all lanes, same word)
         }
         if constexpr (MODE == kFused) {
             const int cx = min(ix, V.W - 1);
@@ -815,7 +843,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8
             }
         }
         if (lane == 0) {
-            if ((FUSED || TOKEN) && (PC ? (blockIdx.x == 0 && wave == kPcProd) : slot == 0))
+            if ((FUSED || TOKEN) && !PC && slot == 0)
                 ctr->blend_kind = TOKEN ? kBlendToken : kBlendFused; // (no k_pool_stats launch behind these: the pool is untouched)
             hdr_count[tile] = (FUSED || TOKEN) ? 0u : hdr_n; // kFused / kToken: the store stays empty
             if (hdr_n)

@@ -86,6 +86,7 @@ constexpr u32 kBlendHalves = 1u;
 constexpr u32 kBlendFused = 2u; // gwbp_blend_scatter: the view was blended AND scattered, its weight store is empty
 constexpr u32 kBlendToken = 3u; // gwbp_blend_tokens: the workspace holds per-(Gaussian, tile) token-quadrant weight sums, no store
 constexpr u32 kOverflowMismatch = 4u; // gwbp_stats::overflow bit 2, see include/gwbp.h
+constexpr u32 kOverflowRingStall = 16u; // bit 4: a wave of the producer / consumer kernel gave up waiting on its LDS ring (internal error)
 constexpr u32 kOverflowTokenGeometry = 8u; // bit 3: gwbp_blend_tokens met a tile that spans more than 2 x 2 tokens
 static_assert(sizeof(Counters) == sizeof(gwbp_stats), "Counters must mirror gwbp_stats");
 

@@ -106,6 +106,8 @@ typedef struct gwbp_stats {
     uint32_t n_headers;   /* (Gaussian, tile) pairs with at least one contributing pixel */
     uint32_t pool_used;   /* weight-pool entries a uniform shard capacity would need: kShards x fullest shard */
     uint32_t overflow;    /* bit0: isect_cap exceeded, bit1: pair_cap exceeded -> results of this view invalid;
+                           * bit4: internal error -- a wave of gwbp_blend_scatter_encoded's producer / consumer form gave up waiting on
+                           * its ring of encoded tiles (the launch ends instead of hanging; the view's result is invalid);
                            * bit3: gwbp_blend_tokens met a tile that spans more than 2 x 2 tokens (precondition violated) -> invalid;
                            * bit2: gwbp_scatter / gwbp_accumulate_d asked for the 256-channel kernel on a view that was
                            * blended WITH GWBP_FLAG_NARROW_SCATTER (no half-tile lists / weight sums): that call left

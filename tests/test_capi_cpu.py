@@ -170,6 +170,34 @@ def test_inline_asm_contracts_of_the_scatter_kernels(tmp_path, opt):
             assert len(found) == 2 and 97 <= found["0"] <= 104 and 97 <= found["1"] <= 112, found
 
 
+def test_producer_consumer_kernel_has_no_lane_masked_loops(tmp_path):
+    """k_blend<kFusedPC> (round 6): its waves wait on an LDS ring.  The first version put a spin loop inside an `if (lane == 0)`
+    and a `break` behind the encode; hipcc's control-flow structuriser turned that into a loop which lane 0 left while lanes
+    1..63 went round again -- the kernel hung the device.  The source now keeps every ring loop wave-uniform (conditions from
+    v_readfirstlane, the LDS atomic alone under the one-lane branch); this checks the RESULT: in the kernel's assembly the only
+    loop whose back edge is controlled by the exec mask (`s_andn2_b64 exec, exec, ...`) is the encoder's staging loop."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    import subprocess
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+             "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics", "-fvisibility=hidden", "-S", "--cuda-device-only"]
+    out = tmp_path / "blend.s"
+    subprocess.check_call([hipcc, *flags, "-o", str(out), os.path.join(_lib.CSRC, "blend.hip")], stderr=subprocess.DEVNULL)
+    body, on = [], False
+    for line in out.read_text().splitlines():
+        if re.match(r"_ZN4gwbp7k_blendILi5ELi12E\S*:", line):
+            on = True
+        elif on and line.startswith(".Lfunc_end"):
+            break
+        elif on:
+            body.append(line)
+    assert len(body) > 500, "k_blend<kFusedPC, 12> not found in the assembly"
+    masked = [ln.strip() for ln in body if "s_andn2_b64 exec, exec" in ln]
+    assert len(masked) <= 1, masked
+    assert sum("s_sleep" in ln for ln in body) == 2  # the producers' and the consumers' wait, both bounded (kPcMaxSpins)
+
+
 def test_the_in_flight_register_check_sees_the_round5_hazard(tmp_path):
     """The checker itself: a compiler-looking copy of a landing register placed between an asm-issued load and its wait must be
     reported, and the same copy behind the wait must not."""

@@ -620,6 +620,35 @@ def test_hip_against_gsplat_capture(dev, fname, cfgname, dim, enc_dim):
         assert rep[k]["rows_over_1e-4"] <= max(1, int(0.002 * rep[k]["rows"])) and rep[k]["max"] <= 1e-2, (k, rep[k])
 
 
+def _token_capture_cases():
+    from util import capture_tool
+    return capture_tool().TOKEN_CASES
+
+
+@pytest.mark.parametrize("fname,cfgname,dim,grid", _token_capture_cases(), ids=[c[0] for c in _token_capture_cases()])
+def test_hip_token_space_against_gsplat_capture(dev, fname, cfgname, dim, grid):
+    """The token-space kernels (round 6) against a capture of REAL gsplat 1.4.0 running the reference's dino loop
+    (backproject.py:242-289), when one has been committed; skipped otherwise (parity unpinned)."""
+    from util import capture_report, capture_tool
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fname)
+    if not os.path.exists(path):
+        pytest.skip(f"{fname} not captured yet (needs CUDA + gsplat==1.4.0)")
+    cap = dict(np.load(path))
+    cfg = syn.CONFIGS[cfgname]
+    g = capture_tool().token_case_inputs(cfgname, dim, grid)
+    t = {k: torch.from_numpy(np.asarray(g[k])).to(dev) for k in ("means", "quats", "scales", "opac", "K", "vms")}
+    toks = [torch.from_numpy(f).to(dev) for f in g["feats"]]
+    assert gsbp_amd.Engine.can_scatter_tokens(toks[0], cfg.height, cfg.width)
+    out, F, d, st = gsbp_amd.create_feature_field(t["means"], t["quats"], t["scales"], t["opac"], t["vms"], t["K"], cfg.width,
+                                                   cfg.height, lambda v: toks[v], dim, reduction="mean", upsample="nearest",
+                                                   return_partials=True)
+    rep = capture_report(cap, out.cpu().numpy(), F.cpu().numpy(), d.cpu().numpy())
+    print("HIP (token space) vs gsplat capture", fname, rep)
+    for k in ("F", "d", "out"):
+        assert rep[k]["p99"] <= 1e-4, (k, rep[k])
+        assert rep[k]["rows_over_1e-4"] <= max(1, int(0.002 * rep[k]["rows"])) and rep[k]["max"] <= 1e-2, (k, rep[k])
+
+
 def test_view_per_stream_schedule_waits_for_late_maps(dev):
     """Stream discipline of the view-per-stream schedule (small scene, <= 32-channel maps -> `independent`): (1) with an
     encoder, the encode kernel must run on the encoder stream behind the `ready` event even though engine 0 is bound to

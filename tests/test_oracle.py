@@ -250,6 +250,31 @@ def test_oracle_against_gsplat_capture(orc, fname, cfgname, dim, enc_dim):
     assert rep.get("radii", {}).get("visible_equal", True), rep["radii"]
 
 
+TOKEN_CAPTURES = capture_tool().TOKEN_CASES
+
+
+@pytest.mark.parametrize("fname,cfgname,dim,grid", TOKEN_CAPTURES, ids=[c[0] for c in TOKEN_CAPTURES])
+def test_oracle_against_gsplat_capture_of_the_dino_loop(orc, fname, cfgname, dim, grid):
+    """The same for the dino loop (backproject.py:242-289: nearest-upsampled tokens, .mean() reductions) -- the case the round-6
+    token-space kernels are compared with; skipped until a capture exists."""
+    from util import capture_report
+    path = os.path.join(os.path.dirname(GOLD), fname)
+    if not os.path.exists(path):
+        pytest.skip(f"{fname} not captured yet (needs CUDA + gsplat==1.4.0): oracle parity stays unpinned")
+    cap = dict(np.load(path))
+    cfg = syn.CONFIGS[cfgname]
+    g = capture_tool().token_case_inputs(cfgname, dim, grid)
+    ups = [torch.nn.functional.interpolate(torch.from_numpy(f).permute(2, 0, 1)[None], size=(cfg.height, cfg.width),
+                                           mode="nearest")[0].permute(1, 2, 0).contiguous().numpy() for f in g["feats"]]
+    out, F, d, _ = orc.backproject_oracle(g["means"], g["quats"], g["scales"], g["opac"], g["vms"], g["K"], cfg.width, cfg.height,
+                                          lambda v: ups[v], dim, reduction="mean")
+    rep = capture_report(cap, out, F, d)
+    print("oracle vs gsplat capture", fname, rep)
+    for k in ("F", "d", "out"):
+        assert rep[k]["p99"] <= 1e-4, (k, rep[k])
+        assert rep[k]["rows_over_1e-4"] <= max(1, int(0.002 * rep[k]["rows"])) and rep[k]["max"] <= 1e-2, (k, rep[k])
+
+
 def test_capture_script_stays_in_sync_with_its_consumers(orc, gold, tmp_path, monkeypatch):
     """tools/capture_gsplat_fixture.py cannot run here (it needs CUDA + gsplat 1.4.0); what CAN rot unnoticed is the
     agreement between the keys it saves and the keys the two consumer tests read (capture_report).  Run its capture()
@@ -310,5 +335,20 @@ def test_capture_script_stays_in_sync_with_its_consumers(orc, gold, tmp_path, mo
                                              lambda v: fe[v], 4)
     rep2 = capture_report(cap2, out2, F2, d2)
     assert cap2["F"].shape == (256, 4) and "F_views" not in cap2 and all(rep2[k]["max"] <= 1e-5 for k in ("F", "d", "out"))
+    # the dino loop (round 6: the token-space kernels' case): an upsampled token map and .mean() reductions through capture()
+    assert [c[0] for c in mod.TOKEN_CASES] == ["gsplat_t1_tokens8x12_d256.npz"]
+    tok = np.random.default_rng(4).standard_normal((g["vms"].shape[0], 3, 4, 8)).astype(np.float32)
+    path3 = str(tmp_path / "gsplat_tok.npz")
+    mod.capture({**{k: g[k] for k in ("means", "quats", "scales", "opac", "K", "vms")}, "feats": tok, "upsample": "nearest",
+                 "reduction": "mean"}, path3, per_view=False)
+    cap3 = dict(np.load(path3))
+    ups = [torch.nn.functional.interpolate(torch.from_numpy(f).permute(2, 0, 1)[None], size=(H0, W0), mode="nearest")[0]
+           .permute(1, 2, 0).contiguous().numpy() for f in tok]
+    out3, F3, d3, _ = orc.backproject_oracle(g["means"], g["quats"], g["scales"], g["opac"], g["vms"], g["K"], W0, H0,
+                                             lambda v: ups[v], 8, reduction="mean")
+    rep3 = capture_report(cap3, out3, F3, d3)
+    assert all(rep3[k]["max"] <= 1e-5 for k in ("F", "d", "out")), rep3
+    tk = mod.token_case_inputs("T1", 256, (8, 12))
+    assert tk["feats"].shape == (syn.CONFIGS["T1"].n_views, 8, 12, 256) and tk["reduction"] == "mean"
     t1 = mod.case_inputs("T1", 64, 16)
     assert t1["feats"].shape[-1] == 64 and t1["encoder"].shape == (64, 16) and t1["means"].shape == (syn.CONFIGS["T1"].n_gaussians, 3)

@@ -12,7 +12,8 @@ runs, once:
 One run pins every kernel family: g0 / T1 (D = 8 / 24: the general scatter kernel), C1 IN FULL (BASELINE config 1: 10 000
 Gaussians, 4 views 400 x 300, D = 32: the fused blend + scatter kernels), T1 with 64-channel maps through a 64 -> 16 encoder
 (backproject_compressed.py:127: encoder kernel + fused small-D kernel), T1 at D = 128 (k_scatter_full) and at D = 256
-(k_scatter_wide).
+(k_scatter_wide); round 6: the DINO loop (backproject.py:242-289: an 8 x 12 x 256 token map nearest-upsampled to the view,
+.mean() reductions) on T1 -- the token-space kernels (k_blend<kToken> + k_token_apply), TOKEN_CASES below.
 
 and commits the resulting .npz DATA files (inputs are already committed; nothing of gsplat's or the reference's source
 travels).  tests/test_oracle.py::test_oracle_against_gsplat_capture (CPU) and tests/test_gpu_parity.py::
@@ -43,7 +44,13 @@ CASES = [
     ("gsplat_t1_d128.npz", "T1", 128, None),
     ("gsplat_t1_d256.npz", "T1", 256, None),
 ]
+# the dino variant: (file, seeded config, token channels, (token rows, token columns)); the capture upsamples the tokens with
+# F.interpolate(mode="nearest") and reduces with .mean() exactly like backproject.py:244-248,263,283
+TOKEN_CASES = [
+    ("gsplat_t1_tokens8x12_d256.npz", "T1", 256, (8, 12)),
+]
 ENCODER_SEED = 7
+TOKEN_SEED0 = 500
 
 
 def case_inputs(cfgname, dim=None, enc_dim=None):
@@ -65,6 +72,18 @@ def case_inputs(cfgname, dim=None, enc_dim=None):
     return inp
 
 
+def token_case_inputs(cfgname, dim, grid):
+    """numpy inputs of a TOKEN_CASES entry: the seeded scene and cameras of `cfgname` and one N(0, 1) token map [h, w, dim] per view
+    (dino's patch tokens are not normalised, backproject.py:242-243)."""
+    import torch
+    inp = case_inputs(cfgname, 1)
+    V = inp["vms"].shape[0]
+    inp["feats"] = np.stack([torch.randn(grid[0], grid[1], dim, generator=torch.Generator().manual_seed(TOKEN_SEED0 + v)).numpy()
+                             for v in range(V)])
+    inp["upsample"], inp["reduction"] = "nearest", "mean"
+    return inp
+
+
 def capture(inp, out_path, per_view=True):
     import torch
     from gsplat import rasterization  # the reference's import (backproject.py:7)
@@ -75,6 +94,10 @@ def capture(inp, out_path, per_view=True):
     t = {k: torch.from_numpy(np.asarray(inp[k])).to(dev) for k in ("means", "quats", "scales", "opac", "K", "vms", "feats")}
     if inp.get("encoder") is not None:  # backproject_compressed.py:127: feats @ encoder, then the D = 16 loop
         t["feats"] = t["feats"] @ torch.from_numpy(np.asarray(inp["encoder"])).to(dev)
+    mean = inp.get("reduction") == "mean"  # dino: .mean() instead of .sum() (backproject.py:263,283)
+    if inp.get("upsample") == "nearest":   # dino: the tokens are upsampled to the view first (backproject.py:244-248)
+        Wv, Hv = int(2 * float(inp["K"][0][2])), int(2 * float(inp["K"][1][2]))  # backproject.py:85-86
+        t["feats"] = torch.nn.functional.interpolate(t["feats"].permute(0, 3, 1, 2), size=(Hv, Wv), mode="nearest").permute(0, 2, 3, 1)
     N, (V, H, W, D) = t["means"].shape[0], t["feats"].shape
     F = torch.zeros(N, D, device=dev)
     d = torch.zeros(N, device=dev)
@@ -84,12 +107,13 @@ def capture(inp, out_path, per_view=True):
         colors = torch.zeros(N, D, device=dev, requires_grad=True)
         out, alphas, meta = rasterization(t["means"], t["quats"], t["scales"], t["opac"], colors, t["vms"][v][None],
                                           t["K"][None], width=W, height=H)
-        (out[0] * t["feats"][v]).sum().backward()
+        prod = out[0] * t["feats"][v]
+        (prod.mean() if mean else prod.sum()).backward()
         Fv.append(colors.grad.detach().clone())
         c3 = torch.zeros(N, 3, device=dev, requires_grad=True)
         out3, _, _ = rasterization(t["means"], t["quats"], t["scales"], t["opac"], c3, t["vms"][v][None], t["K"][None],
                                    width=W, height=H)
-        out3.sum().backward()
+        (out3.mean() if mean else out3.sum()).backward()
         dv.append(c3.grad[:, 0].detach().clone())
         F += Fv[-1]
         d += dv[-1]
@@ -133,6 +157,8 @@ def main():
                 print(fname, "skipped:", e)
                 continue
         capture(inp, os.path.join(GOLD, fname), per_view=(dim or 0) < 128)
+    for fname, cfgname, dim, grid in TOKEN_CASES:
+        capture(token_case_inputs(cfgname, dim, grid), os.path.join(GOLD, fname), per_view=False)
 
 
 if __name__ == "__main__":
