@@ -52,17 +52,32 @@ constexpr int kBatch = 64;
 //            backproject_compressed.py:127-165).  kFusedEnc runs every wave's HBM-bound encoder prologue (0.58 ms worth at C5) and
 //            then its issue-bound blend loop (0.70 ms) back to back, and since all resident waves start together the chip
 //            alternates between an HBM phase with idle issue slots and an issue phase with an idle memory system.  Here one
-//            workgroup per CU holds kPcProd encoder waves (one per SIMD) that do nothing but stream tiles through the matrix
-//            cores into a ring of encoded tiles in LDS (16 KB each), and WAVES - kPcProd blend waves that drain it: the HBM stream
-//            and the blend loops run CONCURRENTLY for the whole launch.  Same encoded pixels, same weights, bit for bit.
+//            workgroup per CU holds kPcProd encoder waves that do nothing but stream tiles through the matrix cores into a ring of
+//            encoded tiles in LDS (16 KB each), and WAVES - kPcProd blend waves that drain it: the HBM stream and the blend loops
+//            run CONCURRENTLY for the whole launch.  Same encoded pixels, same weights, bit for bit.  Measured at C5: the kernel
+//            alone 1.35 -> 1.19 ms, the step 1.34 -> 1.26 ms/view on one box (the north_star's 1.05 would need the blend waves
+//            to run as fast with three waves per SIMD as with four; they are latency-bound, see the wave-mix table below).
 enum BlendMode { kStore = 0, kHalves = 1, kFused = 2, kFusedEnc = 3, kToken = 4, kFusedPC = 5 };
 constexpr int kFusedCh = 16;
 constexpr int kEncWaves = 8;    // kFusedEnc: tiles (waves) per workgroup sharing one LDS copy of the encoder
 constexpr int kEncMaxK = 512;   // ... whose K x 16 floats take at most 32 KB
-constexpr int kPcWaves = 12;    // kFusedPC: waves per workgroup (one workgroup per CU: three 128-register waves per SIMD, which leaves
-                                // every SIMD room for one front-stage wave of another view)
-constexpr int kPcProd = 4;      // ... of which the first four -- one per SIMD -- are encoder (producer) waves
-constexpr int kPcRing = 6;      // ... filling a ring of this many encoded tiles (256 pixels x 16 outputs x 4 B = 16 KB each) in LDS
+// kFusedPC wave mix (tuning knobs; measured at C5 on one box, kernel alone / four views in flight, ms per view --
+// profiles/r6_c5_split.txt: 4 + 8: 1.58 / 1.44, 2 + 10: 1.36 / 1.30, 4 + 12: 1.36 / 1.27, 3 + 12: 1.34 / 1.25, 3 + 13: 1.29 / 1.25,
+// 2 + 14: 1.19 / 1.26, 1 + 12: 1.62 / 1.75 (starved); one wave per tile, kFusedEnc: 1.35 / 1.34).  The blend waves are bound by
+// the LATENCY of their own dependent chains, so their throughput grows with their number, and two encoder waves per CU
+// (2 x 16 KB in flight x 256 CUs) keep up with them.
+#ifndef GWBP_PC_WAVES
+#define GWBP_PC_WAVES 16
+#endif
+#ifndef GWBP_PC_PROD
+#define GWBP_PC_PROD 2
+#endif
+#ifndef GWBP_PC_RING
+#define GWBP_PC_RING 5
+#endif
+constexpr int kPcWaves = GWBP_PC_WAVES; // kFusedPC: waves per workgroup (ONE workgroup per CU: four 128-register waves per SIMD)
+constexpr int kPcProd = GWBP_PC_PROD;   // ... of which the first ones are encoder (producer) waves
+constexpr int kPcRing = GWBP_PC_RING;   // ... filling a ring of this many encoded tiles (256 pixels x 16 outputs x 4 B = 16 KB each) in LDS
 constexpr int kPcTileFloats = kTilePix * kFusedCh;
 // ring slot states: 0 = empty, 1 = claimed (being filled or being read), tile + 2 = holds that tile's encoded pixels
 constexpr u32 kPcEmpty = 0u, kPcBusy = 1u;

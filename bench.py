@@ -64,8 +64,8 @@ def main():
     ap.add_argument("--side-prio", type=int, default=-1, help="HIP priority of the front stage's stream")
     ap.add_argument("--front-prio", choices=("auto", "on", "off"), default="auto",
                     help="raised wave priority for the front-stage kernels (auto: with the 256-channel scatter kernel)")
-    ap.add_argument("--encoder", choices=("fused", "ahead", "blend", "split"), default="blend",
-                    help="C5: encoder inside the small-D scatter kernel's slab staging (fused), a separate kernel one view ahead "
+    ap.add_argument("--encoder", choices=("auto", "fused", "ahead", "blend", "split"), default="auto",
+                    help="C5: auto = what create_feature_field picks (split on images of >= 4096 tiles, else blend); encoder inside the small-D scatter kernel's slab staging (fused), a separate kernel one view ahead "
                          "(ahead), inside the fused blend + scatter kernel's tile prologue (blend: gwbp_blend_scatter_encoded), or "
                          "that kernel's producer / consumer form (split: GWBP_FLAG_SPLIT_ENCODER -- encoder waves and blend waves "
                          "of one persistent launch around an LDS ring of encoded tiles)")
@@ -145,6 +145,9 @@ def main():
 
     cfg = syn.CONFIGS[args.config]
     N, W, H = cfg.n_gaussians, cfg.width, cfg.height
+    if args.encoder == "auto":  # the driver's own rule (backproject.SPLIT_ENCODER_MIN_TILES)
+        tiles = (-(-W // 16)) * (-(-H // 16))
+        args.encoder = "split" if tiles >= gsbp_amd.backproject.SPLIT_ENCODER_MIN_TILES else "blend"
     D_in = cfg.feat_dim
     means, quats, scales, opac = [t.to(dev) for t in syn.activate(syn.make_scene(cfg))]
     K = syn.intrinsics(cfg)

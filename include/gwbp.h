@@ -88,8 +88,8 @@ typedef struct gwbp_caps {
  * the half-tile record lists (15-20 % of its time) when the flag is set, so a view blended WITH the flag must be
  * scattered with it; the other direction (blend without, scatter with) is fine. */
 #define GWBP_FLAG_NARROW_SCATTER 4
-/* gwbp_blend_scatter_encoded runs its producer / consumer form: ONE persistent workgroup per CU whose four encoder waves (one
- * per SIMD) stream tile after tile through the matrix cores into a ring of encoded tiles in LDS while its eight blend waves drain
+/* gwbp_blend_scatter_encoded runs its producer / consumer form: ONE persistent workgroup per CU whose two encoder waves stream
+ * tile after tile through the matrix cores into a ring of encoded tiles in LDS while its fourteen blend waves drain
  * it -- the HBM-bound encoder stream and the issue-bound blend loops run concurrently for the whole launch instead of one after
  * the other in every wave.  Same encoded pixels and weights bit for bit; F and d differ by summation order only.  Pays on images of
  * many tiles per CU (C5: 6700 tiles on 256 CUs); needs gwbp_project of the view to have run on this workspace (the tile counter

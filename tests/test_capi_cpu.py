@@ -186,7 +186,7 @@ def test_producer_consumer_kernel_has_no_lane_masked_loops(tmp_path):
     subprocess.check_call([hipcc, *flags, "-o", str(out), os.path.join(_lib.CSRC, "blend.hip")], stderr=subprocess.DEVNULL)
     body, on = [], False
     for line in out.read_text().splitlines():
-        if re.match(r"_ZN4gwbp7k_blendILi5ELi12E\S*:", line):
+        if re.match(r"_ZN4gwbp7k_blendILi5ELi\d+E\S*:", line):
             on = True
         elif on and line.startswith(".Lfunc_end"):
             break
