@@ -586,10 +586,14 @@ __global__ __launch_bounds__(kOrderThreads) void k_tile_order(const u32 *__restr
                                                               u32 *__restrict__ order, u32 *__restrict__ sweep, int prio)
 {
     front_priority(prio);
-    // the last kernel of gwbp_bin_sort leaves the sort's digit tables and tickets zero for the next call on this workspace
-    // (gwbp_project's memset clears them as well: a view normally starts there)
+#ifdef GWBP_SORT_ONESWEEP
+    // the last kernel of gwbp_bin_sort leaves the look-back sort's digit tables and tickets zero for the next call on this
+    // workspace (gwbp_project's memset clears them as well: a view normally starts there)
     for (int i = threadIdx.x; i < kSweepWords; i += kOrderThreads)
         sweep[i] = 0u;
+#else
+    (void)sweep;
+#endif
     __shared__ u32 s_cnt[1024];
 #pragma unroll
     for (int j = 0; j < 4; ++j)

@@ -34,9 +34,14 @@ def config_entry(cfg):
     bl = next((k for k in avg if "k_blend" in k), None)
     # (maps of at most 16 channels: blend and scatter are ONE kernel, gwbp_blend_scatter = k_blend<2>)
     # (round 5: with an encoder the same kernel also encodes, gwbp_blend_scatter_encoded = k_blend<3, 8>)
-    fused = next((k for k in avg if "k_blend<3" in k), None) or next((k for k in avg if "k_blend<2" in k), None)
-    sc = fused or (max(cands, key=lambda k: avg[k].get("FETCH_SIZE", 0.0)) if cands else bl)
+    # (round 6: its producer / consumer form k_blend<5, 16>; the dino variant's token-space pass k_token_apply<4>)
+    fused = (next((k for k in avg if "k_blend<5" in k), None) or next((k for k in avg if "k_blend<3" in k), None)
+             or next((k for k in avg if "k_blend<2" in k), None))
+    token = next((k for k in avg if "k_token_apply" in k), None)
+    sc = token or fused or (max(cands, key=lambda k: avg[k].get("FETCH_SIZE", 0.0)) if cands else bl)
     bl = fused or bl
+    if token:
+        bl = next((k for k in avg if "k_blend<4" in k), bl)
     a = avg.get(sc, {})
     return {
         "source": f"rocprofv3 --pmc passes of tools/profile_round.sh ({src.rstrip('/').split('/')[-1]}), bench.py --config {cfg} "
@@ -64,7 +69,7 @@ out.update({
               "bytes of wide coalesced streaming reads -> doubled; WRITE_SIZE is exact for 16-B stores and float atomics. "
               "Counter unit is KB.",
 })
-for cfg in ("C2", "C4", "C5"):
+for cfg in ("C2", "C4", "C5", "DINO64", "LSEG480"):
     e = config_entry(cfg)
     if e:
         out[cfg] = e

@@ -3,12 +3,12 @@
 # kernel stats of the same command, and the PMC passes that profiles/traffic.json is made from (tools/make_traffic.py).
 # Counters go in passes of their own, with --kernel-trace only (gpurun refuses --pmc with the other trace domains).
 TAG=${1:-r2x}
-CONFIGS=${2:-"C2 C4 C5 C1"}
+CONFIGS=${2:-"C2 C4 C5 C1 DINO64 LSEG480"}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for C in $CONFIGS; do
-  case $C in C2) STEPS=200;; C4) STEPS=60;; *) STEPS=200;; esac
+  case $C in C2) STEPS=200;; C4) STEPS=60;; DINO64|LSEG480) STEPS=100;; *) STEPS=200;; esac
   if [ -z "$SKIP_BENCH" ]; then
     python3 bench.py --config $C --steps $STEPS > $OUT/bench_${C}_default.json 2> $OUT/bench_${C}_default.err
     tail -c 400 $OUT/bench_${C}_default.json; echo
