@@ -27,6 +27,9 @@ constexpr int kTokCh = 256;       // channels per wave pass: one float4 per lane
 constexpr int kTokPerWave = 16;   // Gaussians (consecutive in depth order) per wave
 constexpr int kTokWaves = 4;
 constexpr int kTokGroup = kTokPerWave * kTokWaves; // Gaussians per workgroup
+#ifndef GWBP_TOKEN_NC
+#define GWBP_TOKEN_NC 4 // 256-channel chunks a wave handles side by side (tuning: 1 and 2 were measured, see the header comment)
+#endif
 constexpr int kTokMaxTiles = 1024;                 // tile columns / rows of the largest view the token path takes (16 384 px)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -50,6 +53,7 @@ struct TokenApplyArgs {
     const float *tokens; // tokens[row * ts_y + col * ts_x + c]
     int64_t ts_y, ts_x;
     int D, W, H;
+    int cgroups; // channel groups of NC x 256 channels handled by DIFFERENT workgroups (1: a wave walks all channels in passes)
     float scale_f, scale_d;
     float *F, *d;
     Counters *ctr;
@@ -76,7 +80,15 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
         s_tr0[i] = A.ymap[min(i * kTile, A.H - 1)];
     __syncthreads();
     const int lane = (int)(threadIdx.x & 63u), wave = (int)uniform(threadIdx.x >> 6);
-    const int64_t i0 = (int64_t)blockIdx.x * kTokGroup + wave * kTokPerWave;
+    // cgroups > 1 (a divisor of 8): the workgroup's channel group is its XCD class modulo the group count, so each XCD's 4 MB L2
+    // keeps re-reading the same slice of the token map
+    u32 cg = 0, group = blockIdx.x;
+    if (A.cgroups > 1) {
+        const u32 xcd = blockIdx.x & 7u, per = 8u / (u32)A.cgroups;
+        cg = xcd % (u32)A.cgroups;
+        group = (blockIdx.x >> 3) * per + xcd / (u32)A.cgroups;
+    }
+    const int64_t i0 = (int64_t)group * kTokGroup + wave * kTokPerWave;
     if (i0 >= A.N)
         return;
     // lanes 0..15: the wave's Gaussians
@@ -94,7 +106,8 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
     if (rest == 0ull)
         return;
     const int quad = lane & 3, sl = lane >> 2; // lane = (slot within a batch of 16, token quadrant qx | qy << 1)
-    const int n_pass = A.D / (kTokCh * NC);
+    const int n_pass = A.cgroups > 1 ? 1 : A.D / (kTokCh * NC);
+    const size_t cg_off = (size_t)cg * (kTokCh * NC);
     auto first_batch = [&](int k) -> float { // the first 16 slots' sums of the wave's k-th Gaussian: 256 contiguous bytes
         const u32 cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k), es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
         return (u32)sl < cnt ? A.omega[(size_t)(es + (u32)sl) * 4 + quad] : 0.f;
@@ -114,8 +127,8 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
             continue; // visible, binned, but no pixel with weight: F and d keep their values (nothing is read or written)
         float dsum = 0.f;
         for (int pass = 0; pass < n_pass; ++pass) {
-            float *frow = A.F + (size_t)gid * (size_t)A.D + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
-            const float *tbase = A.tokens + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
+            float *frow = A.F + (size_t)gid * (size_t)A.D + cg_off + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
+            const float *tbase = A.tokens + cg_off + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
             f4 acc[NC], fold[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c)
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                     for (int c = 0; c < NC; ++c)
                         fold[c] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(frow + c * kTokCh));
                 }
-                if (pass == 0)
+                if (pass == 0 && cg == 0)
                     dsum += om;
                 // the token under this lane's (tile, quadrant): first token of the tile + (qx, qy); only dereferenced where om != 0,
                 // i.e. where the blend found a pixel of that token
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                 fold[c].w = __builtin_fmaf(A.scale_f, acc[c].w, fold[c].w);
                 __builtin_nontemporal_store(fold[c], reinterpret_cast<f4 *>(frow + c * kTokCh));
             }
-            if (pass == 0 && A.d) { // the wave owns d[gid] as well: plain read-modify-write
+            if (pass == 0 && cg == 0 && A.d) { // the wave owns d[gid] as well: plain read-modify-write
                 const float tot = wave_sum(dsum);
                 if (lane == 0)
                     A.d[gid] = __builtin_fmaf(A.scale_d, tot, A.d[gid]);
@@ -222,13 +235,21 @@ int launch_token_apply(const Layout &L, const Ws &W, const ViewDev &V, const flo
     A.ymap = ymap, A.xmap = xmap, A.tokens = tokens, A.ts_y = ts_y, A.ts_x = ts_x;
     A.D = D, A.W = V.W, A.H = V.H, A.scale_f = scale_f, A.scale_d = scale_d, A.F = F, A.d = d;
     A.ctr = W.counters;
-    const int64_t blocks = (L.n + kTokGroup - 1) / kTokGroup;
+    // chunks per wave: as many as divide D (4, 2, 1); GWBP_TOKEN_NC (tuning) caps it, and the channel groups that leaves are
+    // spread over the XCD classes when their number divides 8
+    int nc = D % (4 * kTokCh) == 0 ? 4 : D % (2 * kTokCh) == 0 ? 2 : 1;
+    if (nc > GWBP_TOKEN_NC)
+        nc = GWBP_TOKEN_NC;
+    const int groups_ch = D / (kTokCh * nc);
+    A.cgroups = (nc < 4 && groups_ch > 1 && 8 % groups_ch == 0 && GWBP_TOKEN_NC < 4) ? groups_ch : 1;
+    const int64_t n_groups = (L.n + kTokGroup - 1) / kTokGroup;
+    const int64_t blocks = A.cgroups > 1 ? ((n_groups + 8 / A.cgroups - 1) / (8 / A.cgroups)) * 8 : n_groups;
     if (blocks > 0x7FFFFFFFll)
         return set_error(GWBP_EINVAL, "gwbp_scatter_tokens: grid too large");
     const dim3 grid((unsigned)blocks), block(64 * kTokWaves);
-    if (D % (4 * kTokCh) == 0)
+    if (nc == 4)
         hipLaunchKernelGGL(k_token_apply<4>, grid, block, 0, s, A);
-    else if (D % (2 * kTokCh) == 0)
+    else if (nc == 2)
         hipLaunchKernelGGL(k_token_apply<2>, grid, block, 0, s, A);
     else
         hipLaunchKernelGGL(k_token_apply<1>, grid, block, 0, s, A);

@@ -414,7 +414,7 @@ def main():
         # view"; n_visible (survives culling) is what its formula and probe number use and is ~45 % larger at C2.  n_touched =
         # Gaussians with d_v > 0, counted per timed view by the post-run check pass (exact, outside the timed region).
         n_touched = (checked or {}).get("n_touched_per_view")
-        b_strict = 4.0 * H * W * d_read + 8.0 * n_touched * (D + 1) if n_touched else None
+        b_strict = 4.0 * map_px * d_read + 8.0 * n_touched * (D + 1) if n_touched else None
         # PMC counters cannot be collected from inside this process: `traffic` is the HBM byte count per launch of the
         # SAME kernel and workload from the committed rocprofv3 --pmc passes (tools/profile_round.sh, separate runs)
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
