@@ -431,6 +431,9 @@ def main():
                           "k_scatter_wide" if scatter_choice == "wide" else
                           "k_scatter_full" if (D % 128 == 0 or D <= 64) else "k_scatter")
         traffic, traffic_source, valu_insts = committed_traffic(args.config, scatter_kernel)
+        # bytes added by fp32 atomics per launch: one D-wide flush (+ d) per contributing (Gaussian, tile) record; the token-space
+        # pass uses none (one plain read-modify-write per F row)
+        atomic_bytes = 0.0 if token_grid is not None else n_hdr * (D + 1) * 4.0
         out = {
             "metric": "Gaussian-pixel-features/sec", "value": total_pairs * D / elapsed,
             "unit": "Gaussian-pixel-features/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -469,12 +472,12 @@ def main():
                          "pipeline_achieved_GBs": b_view / (elapsed / args.steps) / 1e9,
                          # second ceiling of the same kernel: fp32 atomics execute memory-side at ~1.3 TB/s of added
                          # bytes chip-wide (MI355X_MICROARCH.md, Global float atomics); one flush per (Gaussian, tile)
-                         "atomic_added_GBs": n_hdr * (D + 1) * 4.0 / (t_scatter * 1e-3) / 1e9,
+                         "atomic_added_GBs": atomic_bytes / (t_scatter * 1e-3) / 1e9,
                          "atomic_peak_GBs": 1300.0,
-                         "atomic_frac": n_hdr * (D + 1) * 4.0 / (t_scatter * 1e-3) / 1e9 / 1300.0,
+                         "atomic_frac": atomic_bytes / (t_scatter * 1e-3) / 1e9 / 1300.0,
                          # ... which makes it a FLOOR of the launch time for one flush per (Gaussian, tile), whatever the
                          # kernel's loop costs (the op rate of the memory-side atomic units)
-                         "atomic_floor_ms": n_hdr * (D + 1) * 4.0 / 1300.0e9 * 1e3,
+                         "atomic_floor_ms": atomic_bytes / 1300.0e9 * 1e3,
                          # third ceiling, the one the 256-channel kernel's loop actually runs into:
                          # every (pair, channel) product reads 4 B of the LDS slab; MI355X_MICROARCH.md: ~150 TB/s
                          # aggregate for ds_read_b64/b128 with every CU streaming
