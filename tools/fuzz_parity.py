@@ -18,12 +18,14 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device("cuda:0")
 orc.build()
-DIMS = [1, 3, 4, 7, 8, 12, 16, 17, 32, 40, 64, 65, 100, 128, 130, 256, 384, 512, 768]
+DIMS = [1, 3, 4, 7, 8, 12, 16, 17, 32, 40, 64, 65, 100, 128, 130, 256, 384, 512, 768, 1024]
 bad = 0
 n_fused = 0
 n_enc = 0
 n_render = 0
 n_px = 0
+n_tok = 0
+n_split = 0
 t0 = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
@@ -49,6 +51,8 @@ for case in range(n_cases):
     up = rng.choice([None, None, "nearest", "bilinear"])
     if up is not None:  # a low-resolution map; the oracle gets F.interpolate's materialised version
         lh, lw = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        if up == "nearest" and D % 256 == 0 and rng.random() < 0.7:  # round 6: coarse enough for the token-space path
+            lh, lw = int(rng.integers(1, max(2, H // 16 + 1))), int(rng.integers(1, max(2, W // 16 + 1)))
         low = torch.randn(lh, lw, D, generator=g)
         if D < 4:
             low = low.abs()
@@ -83,6 +87,11 @@ for case in range(n_cases):
     eng.set_narrow_scatter(not wide)
     view = eng.view(vm, K, W, H)
     fused = enc is None and up is None and bool(rng.integers(0, 2)) and gsbp_amd.Engine.can_blend_scatter(fd)
+    # round 6: nearest-upsampled maps whose texels cover a tile go through token space (gwbp_blend_tokens + gwbp_scatter_tokens);
+    # the encoder-fused kernel in its producer / consumer form (GWBP_FLAG_SPLIT_ENCODER) on every second encoder case
+    tok = up == "nearest" and gsbp_amd.Engine.can_scatter_tokens(fd, H, W) and rng.random() < 0.8
+    split = enc is not None and bool(rng.integers(0, 2))
+    eng.set_split_encoder(split)
     for attempt in range(4):  # a capacity overflow invalidates the view: grow the workspace and run it again
         F = torch.zeros(n, D, device=dev)
         d = torch.zeros(n, device=dev)
@@ -94,6 +103,11 @@ for case in range(n_cases):
             eng.project(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
             eng.bin_sort(view)
             eng.blend_scatter(view, fd, F, d)
+        elif tok:
+            eng.project(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
+            eng.bin_sort(view)
+            eng.blend_tokens(view, fd.shape[0], fd.shape[1])
+            eng.scatter_tokens(view, fd, F, d)
         elif up is None:
             eng.backproject_view(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev), fd, F, d)
         else:
@@ -105,8 +119,11 @@ for case in range(n_cases):
             break
         eng.grow(eng.stats())
         eng.set_narrow_scatter(not wide)
+        eng.set_split_encoder(split)
     n_fused += int(fused)
     n_enc += int(enc is not None)
+    n_tok += int(tok)
+    n_split += int(split)
     st = eng.stats()
     Fr, dr = np.zeros((n, D), np.float64), np.zeros(n, np.float64)
     info = orc.backproject_view(means.numpy(), quats.numpy(), scales.numpy(), opac.numpy(), vm.numpy(), K.numpy(), W, H,
@@ -120,7 +137,7 @@ for case in range(n_cases):
     if ok and rng.random() < 0.5:
         Dr = int(rng.choice([5, 20, 64, 127, 128, 132, 200, 256, 260, 384, 512, 516, 708, 1024]))
         cols = torch.randn(n, Dr, generator=g)
-        if fused or enc is not None:  # those paths left no weight store behind
+        if fused or enc is not None or tok:  # those paths left no weight store behind
             eng.blend_weights(view)
         out = eng.render(view, cols.to(dev)).cpu().numpy()
         rp = orc.project(means.numpy(), quats.numpy(), scales.numpy(), vm.numpy(), K.numpy(), W, H)
@@ -147,8 +164,8 @@ for case in range(n_cases):
             print(f"render_pixels D={Dp}: max error {er:.2e} alpha identical {same_alpha}", flush=True)
     if not ok:
         bad += 1
-        print(f"FAIL case {seed0 + case}: N={n} {W}x{H} D={D} s0={s0:.4f} {layout} up={up} wide={wide} tight={tight} fused={fused} enc={None if enc is None else tuple(enc.shape)} "
+        print(f"FAIL case {seed0 + case}: N={n} {W}x{H} D={D} s0={s0:.4f} {layout} up={up} wide={wide} tight={tight} fused={fused} tok={tok} split={split} enc={None if enc is None else tuple(enc.shape)} "
               f"pairs {st['n_pairs']}/{info['n_pairs']} eF={eF:.2e} ed={ed:.2e} overflow={st['overflow']}", flush=True)
-print(f"{n_cases} cases ({n_fused} through the fused blend+scatter kernel, {n_enc} through the encoder-fused one, {n_render} also rendered forward, {n_px} through the pixel-parallel render), {bad} failures, "
+print(f"{n_cases} cases ({n_fused} through the fused blend+scatter kernel, {n_enc} through the encoder-fused one ({n_split} of them in its producer / consumer form), {n_tok} through token space, {n_render} also rendered forward, {n_px} through the pixel-parallel render), {bad} failures, "
       f"{time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
