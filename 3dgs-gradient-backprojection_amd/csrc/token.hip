@@ -18,7 +18,10 @@
 // Work map: one wave walks 16 consecutive Gaussians of the depth order (= the emit order: their sums are contiguous), one Gaussian at
 // a time over ALL its channels (up to four 256-channel chunks side by side), with the next Gaussian's sums requested a Gaussian
 // ahead.  (First version, measured at 2.17 ms per C2-geometry view at D = 1024: one (Gaussian, 256-channel chunk) per wave
-// iteration with the chunk tied to the XCD so that each L2 kept one 4 MB slice of the token map -- 3.4 M short dependent chains.)
+// iteration with the chunk tied to the XCD so that each L2 kept one 4 MB slice of the token map -- 3.4 M short dependent chains.
+// The same XCD-local channel groups in THIS kernel -- GWBP_TOKEN_NC = 1 / 2: one / two chunks per wave, the rest of the channels
+// on the other XCD classes -- measured on one box beside the all-channels form: alone 1.55-1.66 / 1.32-1.35 against 1.25-1.27 ms,
+// in the pipeline 2.26-2.36 / 1.97 against 1.91: the L2 locality does not pay for the 4x / 2x number of dependent chains.)
 #include "gwbp_dev.h"
 
 namespace gwbp {
