@@ -697,6 +697,10 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
                         eng.scatter(view, feats, F, d, sf, sd, upsample=upsample)
                     eng.accumulate_stats(accum)
                 stats = Engine.decode_stats(accum)  # synchronises
+            if stats["overflow"] & 16:
+                raise RuntimeError("a wave of gwbp_blend_scatter_encoded's producer / consumer kernel gave up waiting on its LDS ring "
+                                   "(gwbp_stats.overflow bit 4): internal error, F and d are incomplete -- rerun with "
+                                   "encoder_split=False and report it")
             if stats["overflow"] & 8:
                 raise RuntimeError("gwbp_blend_tokens met a tile that spans more than 2 x 2 texels (gwbp_stats.overflow bit 3): "
                                    "the map is finer than Engine.token_geometry_ok() admitted")
