@@ -63,7 +63,8 @@ constexpr int kEncWaves = 8;    // kFusedEnc: tiles (waves) per workgroup sharin
 constexpr int kEncMaxK = 512;   // ... whose K x 16 floats take at most 32 KB
 // kFusedPC wave mix (tuning knobs; measured at C5 on one box, kernel alone / four views in flight, ms per view --
 // profiles/r6_c5_split.txt: 4 + 8: 1.58 / 1.44, 2 + 10: 1.36 / 1.30, 4 + 12: 1.36 / 1.27, 3 + 12: 1.34 / 1.25, 3 + 13: 1.29 / 1.25,
-// 2 + 14: 1.19 / 1.26, 1 + 12: 1.62 / 1.75 (starved); one wave per tile, kFusedEnc: 1.35 / 1.34).  The blend waves are bound by
+// 2 + 14: 1.19 / 1.26, 1 + 12: 1.62 / 1.75 (starved); one wave per tile, kFusedEnc: 1.35 / 1.34; on the shipped mix, ring 3 / 6,
+// non-temporal map loads, a shorter poll interval and 2 + 13 were all within the noise of a second box, ring 6 worse).  The blend waves are bound by
 // the LATENCY of their own dependent chains, so their throughput grows with their number, and two encoder waves per CU
 // (2 x 16 KB in flight x 256 CUs) keep up with them.
 #ifndef GWBP_PC_WAVES
