@@ -52,6 +52,9 @@ CONFIGS: Dict[str, Config] = {
     # small shapes used by the parity tests and smoke()
     "T0": Config("T0", 512, 2, 96, 64, 8, 0.06, False),
     "T1": Config("T1", 4_000, 2, 200, 136, 24, 0.04, True),
+    # T1 with a dino-shaped map: 8 x 12 x 256 tokens (17 x 16.7 pixel texels: at least a tile), nearest, .mean() -> token space
+    "T1D": Config("T1D", 4_000, 2, 200, 136, 256, 0.04, True, lowres=(8, 12), upsample="nearest", reduction="mean",
+                  normalize=False),
 }
 
 

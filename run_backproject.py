@@ -72,6 +72,10 @@ def main():
         K, viewmats, W, H, dim = syn.intrinsics(cfg), syn.make_cameras(cfg), cfg.width, cfg.height, cfg.feat_dim
         encoder = syn.make_encoder(cfg).to(dev) if cfg.encoder_dim else None
 
+        # (DINO64 / LSEG480: the network's own low-resolution map, upsampled inside the kernels like the reference's F.interpolate)
+        upsample = cfg.upsample
+        reduction = cfg.reduction if cfg.lowres else ("mean" if args.feature == "dino" else "sum")
+
         def feature_fn(v):
             return syn.make_feature_map(cfg, v, device=dev)
     else:
@@ -89,11 +93,19 @@ def main():
         encoder = torch.load(args.encoder).to(dev).float() if args.encoder else None
         first = torch.load(os.path.join(args.feature_maps, images[0].name + ".pt"))
         dim = first.shape[-1]
+        # A map at the network's resolution is upsampled the way the reference does it -- bilinear for lseg (backproject.py:110-112),
+        # nearest for dino's patch tokens (:244-248) -- INSIDE the kernels (dino maps whose tokens cover a tile: token space); with an
+        # encoder the map is materialised first (the encoder-fused kernels read full-resolution pixels)
+        mode = "nearest" if args.feature == "dino" else "bilinear"
+        upsample = mode if (tuple(first.shape[:2]) != (H, W) and encoder is None) else None
+        reduction = "mean" if args.feature == "dino" else "sum"  # backproject.py:263,283 vs :127,145
 
         def feature_fn(v):
             f = torch.load(os.path.join(args.feature_maps, images[v].name + ".pt")).to(dev).float()
-            return f if f.shape[:2] == (H, W) else torch.nn.functional.interpolate(
-                f.permute(2, 0, 1)[None], size=(H, W), mode="bilinear")[0].permute(1, 2, 0)
+            if upsample is not None or tuple(f.shape[:2]) == (H, W):
+                return f
+            kw = {"align_corners": False} if mode == "bilinear" else {}
+            return torch.nn.functional.interpolate(f.permute(2, 0, 1)[None], size=(H, W), mode=mode, **kw)[0].permute(1, 2, 0)
 
     # backproject.py:323-325: splats_optimized = prune_by_gradients(splats); test_proper_pruning(splats, splats_optimized);
     # the field is then built on the PRUNED scene.  The mask costs one blend per view (no scatter).  Under a process group
@@ -122,10 +134,9 @@ def main():
         report_and_check(keep)
         means, quats, scales, opac = means[keep], quats[keep], scales[keep], opac[keep]
 
-    reduction = "mean" if args.feature == "dino" else "sum"  # backproject.py:263,283 vs :127,145
     out, F, d, stats = gsbp_amd.create_feature_field(means, quats, scales, opac, viewmats, K, W, H, feature_fn, dim,
                                                      reduction=reduction, encoder=encoder, return_partials=True,
-                                                     verbose=True)
+                                                     verbose=True, upsample=upsample)
     if args.prune_by_product and not args.no_prune:
         # "the mask comes free from the fused kernel" -- d is the all-reduced denominator of every Gaussian,
         # identical on every rank

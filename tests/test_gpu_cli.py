@@ -77,3 +77,24 @@ def test_cli_two_ranks_shard_sweep_check_and_build(dev, tmp_path):
     assert torch.equal(ka, kb)
     fa, fb = torch.load(a / "features_lseg.pt"), torch.load(b / "features_lseg.pt")
     assert fa.shape == fb.shape and float((fa - fb).abs().max()) <= 1e-4
+
+
+def test_cli_dino_shaped_map_goes_through_token_space(dev, tmp_path):
+    """`run_backproject.py --synthetic T1D` (an 8 x 12 x 256 token map, nearest, .mean(): the dino script's shape at test size):
+    the CLI hands the network-resolution map to the driver with upsample="nearest", which takes the token-space kernels; the saved
+    field equals the pixel-slab path's (token_space=False) run in-process on the same seeded inputs."""
+    import torch
+    import gsbp_amd
+    from gsbp_amd import synthetic as syn
+    out_dir = tmp_path / "tok"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_backproject.py"), "--synthetic", "T1D", "--results-dir", str(out_dir),
+                        "--feature", "dino", "--no-prune"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    got = torch.load(out_dir / "features_dino.pt")
+    cfg = syn.CONFIGS["T1D"]
+    g = [t.to(dev) for t in syn.activate(syn.make_scene(cfg))]
+    ref = gsbp_amd.create_feature_field(*g, syn.make_cameras(cfg).to(dev), syn.intrinsics(cfg).to(dev), cfg.width, cfg.height,
+                                        lambda v: syn.make_feature_map(cfg, v, device=dev), cfg.feat_dim, reduction="mean",
+                                        upsample="nearest", token_space=False)
+    assert tuple(got.shape) == (cfg.n_gaussians, cfg.feat_dim)
+    assert float((got.to(dev) - ref).abs().max()) <= 2e-5
