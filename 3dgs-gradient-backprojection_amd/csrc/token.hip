@@ -19,9 +19,9 @@
 // a time over ALL its channels (up to four 256-channel chunks side by side), with the next Gaussian's sums requested a Gaussian
 // ahead.  (First version, measured at 2.17 ms per C2-geometry view at D = 1024: one (Gaussian, 256-channel chunk) per wave
 // iteration with the chunk tied to the XCD so that each L2 kept one 4 MB slice of the token map -- 3.4 M short dependent chains.
-// The same XCD-local channel groups in THIS kernel -- GWBP_TOKEN_NC = 1 / 2: one / two chunks per wave, the rest of the channels
-// on the other XCD classes -- measured on one box beside the all-channels form: alone 1.55-1.66 / 1.32-1.35 against 1.25-1.27 ms,
-// in the pipeline 2.26-2.36 / 1.97 against 1.91: the L2 locality does not pay for the 4x / 2x number of dependent chains.)
+// The same XCD-local channel groups in the one-wave-per-Gaussian kernel -- one / two chunks per wave, the rest of the channels on
+// the other XCD classes -- measured on one box beside the all-channels form: alone 1.55-1.66 / 1.32-1.35 against 1.25-1.27 ms, in
+// the pipeline 2.26-2.36 / 1.97 against 1.91: that L2 locality does not pay for the 4x / 2x number of dependent chains.)
 #include "gwbp_dev.h"
 
 namespace gwbp {
@@ -30,9 +30,6 @@ constexpr int kTokCh = 256;       // channels per wave pass: one float4 per lane
 constexpr int kTokPerWave = 16;   // Gaussians (consecutive in depth order) per wave
 constexpr int kTokWaves = 4;
 constexpr int kTokGroup = kTokPerWave * kTokWaves; // Gaussians per workgroup
-#ifndef GWBP_TOKEN_NC
-#define GWBP_TOKEN_NC 4 // 256-channel chunks a wave handles side by side (tuning: 1 and 2 were measured, see the header comment)
-#endif
 constexpr int kTokMaxTiles = 1024;                 // tile columns / rows of the largest view the token path takes (16 384 px)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -55,8 +52,8 @@ struct TokenApplyArgs {
     const int32_t *ymap, *xmap;
     const float *tokens; // tokens[row * ts_y + col * ts_x + c]
     int64_t ts_y, ts_x;
+    const u32 *sorted_tiles, *sorted_gids; // the intersections in (tile, depth) order: tile id, Gaussian
     int D, W, H;
-    int cgroups; // channel groups of NC x 256 channels handled by DIFFERENT workgroups (1: a wave walks all channels in passes)
     float scale_f, scale_d;
     float *F, *d;
     Counters *ctr;
@@ -65,7 +62,7 @@ struct TokenApplyArgs {
 // One wave = one Gaussian at a time, ALL its channels: NC chunks of 256 channels side by side (NC x float4 per lane; D = 1024:
 // NC = 4, one pass), so the Gaussian's weight sums are read and decoded once and every token row read / F row read-modify-write
 // of the Gaussian is in flight together.  The sums of the NEXT Gaussian are requested before this one is worked on.
-template <int NC>
+template <int NC, bool TILE_ORDER>
 __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A)
 {
     if (A.ctr->blend_kind != kBlendToken) { // the view in this workspace was not blended by gwbp_blend_tokens
@@ -75,6 +72,8 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
     }
     // first token column / row of every tile column / row (the index maps at the tiles' first pixels): a few hundred ints that
     // every entry's token lookup reads -- from LDS, not through a dependent global load in front of the token row reads
+    if (TILE_ORDER && blockIdx.x * (u32)(64 * kTokWaves) >= A.ctr->n_isect)
+        return; // launched for the capacity (the intersection count lives on the device): blocks beyond the data leave at once
     __shared__ int s_tc0[kTokMaxTiles], s_tr0[kTokMaxTiles];
     const int tile_w = (A.W + kTile - 1) / kTile, tile_h = (A.H + kTile - 1) / kTile;
     for (int i = threadIdx.x; i < tile_w; i += 64 * kTokWaves)
@@ -83,34 +82,47 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
         s_tr0[i] = A.ymap[min(i * kTile, A.H - 1)];
     __syncthreads();
     const int lane = (int)(threadIdx.x & 63u), wave = (int)uniform(threadIdx.x >> 6);
-    // cgroups > 1 (a divisor of 8): the workgroup's channel group is its XCD class modulo the group count, so each XCD's 4 MB L2
-    // keeps re-reading the same slice of the token map
-    u32 cg = 0, group = blockIdx.x;
-    if (A.cgroups > 1) {
-        const u32 xcd = blockIdx.x & 7u, per = 8u / (u32)A.cgroups;
-        cg = xcd % (u32)A.cgroups;
-        group = (blockIdx.x >> 3) * per + xcd / (u32)A.cgroups;
-    }
-    const int64_t i0 = (int64_t)group * kTokGroup + wave * kTokPerWave;
-    if (i0 >= A.N)
-        return;
-    // lanes 0..15: the wave's Gaussians
+    // WHICH Gaussians a wave takes.  Product: 16 consecutive Gaussians of the depth order (= the emit order; screen positions at
+    // random, so their token rows are gathered from all over the 16 MB map: L2 hit rate 0.52, the rest from the Infinity Cache).
+    // TILE_ORDER (-DGWBP_TOKEN_TILE_ORDER, built to test whether those gathers bind): the wave takes 64 consecutive entries of
+    // the (tile, depth)-sorted intersection list and works on the Gaussians whose HOME tile -- the first tile of their rectangle,
+    // emit slot 0 -- is the entry's tile: every Gaussian exactly once, neighbours on the screen back to back, consecutive
+    // Gaussians read the SAME few token rows.  Measured on one box (DINO64): alone 1.266 against 1.285 ms, beside two fronts 1.86
+    // against 1.83 -- the gathers do not bind; what does is the latency chain of one F row read-modify-write per Gaussian and
+    // wave (4.45 GB of random 4-KB rows at 3.5 TB/s, one row in flight per wave).
     u32 m_gid = 0, m_cnt = 0, m_es = 0, m_rx = 0, m_ry = 0;
-    if (lane < kTokPerWave && i0 + lane < A.N) {
-        m_gid = A.order[i0 + lane];
-        m_cnt = A.touched[m_gid];
-        if (m_cnt) {
-            m_es = A.estart[m_gid];
-            const uint2 rc = A.rect[m_gid];
-            m_rx = rc.x, m_ry = rc.y;
+    if constexpr (TILE_ORDER) {
+        const u32 n_isect = A.ctr->n_isect;
+        const u32 i0 = (blockIdx.x * (u32)kTokWaves + (u32)wave) * 64u;
+        if (i0 >= n_isect)
+            return;
+        if (i0 + (u32)lane < n_isect) {
+            const u32 gid = A.sorted_gids[i0 + lane], tile = A.sorted_tiles[i0 + lane];
+            const uint2 rc = A.rect[gid];
+            if (tile == (rc.y & 0xFFFFu) * (u32)tile_w + (rc.x & 0xFFFFu)) {
+                m_gid = gid, m_cnt = A.touched[gid], m_es = A.estart[gid];
+                m_rx = rc.x, m_ry = rc.y;
+            }
+        }
+    } else {
+        const int64_t i0 = ((int64_t)blockIdx.x * kTokWaves + wave) * kTokPerWave;
+        if (i0 >= A.N)
+            return;
+        if (lane < kTokPerWave && i0 + lane < A.N) {
+            m_gid = A.order[i0 + lane];
+            m_cnt = A.touched[m_gid];
+            if (m_cnt) {
+                m_es = A.estart[m_gid];
+                const uint2 rc = A.rect[m_gid];
+                m_rx = rc.x, m_ry = rc.y;
+            }
         }
     }
     u64 rest = __ballot(m_cnt != 0u);
     if (rest == 0ull)
         return;
     const int quad = lane & 3, sl = lane >> 2; // lane = (slot within a batch of 16, token quadrant qx | qy << 1)
-    const int n_pass = A.cgroups > 1 ? 1 : A.D / (kTokCh * NC);
-    const size_t cg_off = (size_t)cg * (kTokCh * NC);
+    const int n_pass = A.D / (kTokCh * NC);
     auto first_batch = [&](int k) -> float { // the first 16 slots' sums of the wave's k-th Gaussian: 256 contiguous bytes
         const u32 cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k), es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
         return (u32)sl < cnt ? A.omega[(size_t)(es + (u32)sl) * 4 + quad] : 0.f;
@@ -130,8 +142,8 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
             continue; // visible, binned, but no pixel with weight: F and d keep their values (nothing is read or written)
         float dsum = 0.f;
         for (int pass = 0; pass < n_pass; ++pass) {
-            float *frow = A.F + (size_t)gid * (size_t)A.D + cg_off + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
-            const float *tbase = A.tokens + cg_off + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
+            float *frow = A.F + (size_t)gid * (size_t)A.D + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
+            const float *tbase = A.tokens + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
             f4 acc[NC], fold[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c)
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                     for (int c = 0; c < NC; ++c)
                         fold[c] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(frow + c * kTokCh));
                 }
-                if (pass == 0 && cg == 0)
+                if (pass == 0)
                     dsum += om;
                 // the token under this lane's (tile, quadrant): first token of the tile + (qx, qy); only dereferenced where om != 0,
                 // i.e. where the blend found a pixel of that token
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                 fold[c].w = __builtin_fmaf(A.scale_f, acc[c].w, fold[c].w);
                 __builtin_nontemporal_store(fold[c], reinterpret_cast<f4 *>(frow + c * kTokCh));
             }
-            if (pass == 0 && cg == 0 && A.d) { // the wave owns d[gid] as well: plain read-modify-write
+            if (pass == 0 && A.d) { // the wave owns d[gid] as well: plain read-modify-write
                 const float tot = wave_sum(dsum);
                 if (lane == 0)
                     A.d[gid] = __builtin_fmaf(A.scale_d, tot, A.d[gid]);
@@ -238,24 +250,26 @@ int launch_token_apply(const Layout &L, const Ws &W, const ViewDev &V, const flo
     A.ymap = ymap, A.xmap = xmap, A.tokens = tokens, A.ts_y = ts_y, A.ts_x = ts_x;
     A.D = D, A.W = V.W, A.H = V.H, A.scale_f = scale_f, A.scale_d = scale_d, A.F = F, A.d = d;
     A.ctr = W.counters;
-    // chunks per wave: as many as divide D (4, 2, 1); GWBP_TOKEN_NC (tuning) caps it, and the channel groups that leaves are
-    // spread over the XCD classes when their number divides 8
-    int nc = D % (4 * kTokCh) == 0 ? 4 : D % (2 * kTokCh) == 0 ? 2 : 1;
-    if (nc > GWBP_TOKEN_NC)
-        nc = GWBP_TOKEN_NC;
-    const int groups_ch = D / (kTokCh * nc);
-    A.cgroups = (nc < 4 && groups_ch > 1 && 8 % groups_ch == 0 && GWBP_TOKEN_NC < 4) ? groups_ch : 1;
-    const int64_t n_groups = (L.n + kTokGroup - 1) / kTokGroup;
-    const int64_t blocks = A.cgroups > 1 ? ((n_groups + 8 / A.cgroups - 1) / (8 / A.cgroups)) * 8 : n_groups;
+    // 256-channel chunks a wave handles side by side: as many as divide D (4, 2, 1)
+    const int nc = D % (4 * kTokCh) == 0 ? 4 : D % (2 * kTokCh) == 0 ? 2 : 1;
+    const int fin = sort_passes(V.tile_w * V.tile_h) & 1; // where the tile sort left its result
+    A.sorted_tiles = W.keys[fin], A.sorted_gids = W.vals[fin];
+#ifdef GWBP_TOKEN_TILE_ORDER // (measured: see k_token_apply)
+    constexpr bool kTileOrder = true;
+    const int64_t blocks = (L.isect_cap + 64 * kTokWaves - 1) / (64 * kTokWaves);
+#else
+    constexpr bool kTileOrder = false;
+    const int64_t blocks = (L.n + kTokGroup - 1) / kTokGroup;
+#endif
     if (blocks > 0x7FFFFFFFll)
         return set_error(GWBP_EINVAL, "gwbp_scatter_tokens: grid too large");
     const dim3 grid((unsigned)blocks), block(64 * kTokWaves);
     if (nc == 4)
-        hipLaunchKernelGGL(k_token_apply<4>, grid, block, 0, s, A);
+        hipLaunchKernelGGL((k_token_apply<4, kTileOrder>), grid, block, 0, s, A);
     else if (nc == 2)
-        hipLaunchKernelGGL(k_token_apply<2>, grid, block, 0, s, A);
+        hipLaunchKernelGGL((k_token_apply<2, kTileOrder>), grid, block, 0, s, A);
     else
-        hipLaunchKernelGGL(k_token_apply<1>, grid, block, 0, s, A);
+        hipLaunchKernelGGL((k_token_apply<1, kTileOrder>), grid, block, 0, s, A);
     return check_hip(hipGetLastError(), "token_apply launch");
 }
 
