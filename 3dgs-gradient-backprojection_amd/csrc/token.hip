@@ -72,6 +72,11 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
     }
     // first token column / row of every tile column / row (the index maps at the tiles' first pixels): a few hundred ints that
     // every entry's token lookup reads -- from LDS, not through a dependent global load in front of the token row reads
+    // An intersection-capacity overflow leaves NO emit positions behind (k_emit returns at once, estart[] holds whatever the depth
+    // sort left there): the view is invalid anyway (the host grows the workspace and runs it again) and nothing may be read
+    // through estart.
+    if (A.ctr->overflow & 1u)
+        return;
     if (TILE_ORDER && blockIdx.x * (u32)(64 * kTokWaves) >= A.ctr->n_isect)
         return; // launched for the capacity (the intersection count lives on the device): blocks beyond the data leave at once
     __shared__ int s_tc0[kTokMaxTiles], s_tr0[kTokMaxTiles];

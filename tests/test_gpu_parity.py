@@ -933,6 +933,26 @@ def test_driver_grows_the_workspace_on_overflow(dev, pipeline):
     assert np.abs(da.cpu().numpy() - db.cpu().numpy()).max() <= 1e-5 * float(db.max())
 
 
+@pytest.mark.parametrize("pipeline", [True, False], ids=["pipelined", "serial"])
+def test_token_space_driver_survives_an_intersection_overflow(dev, pipeline):
+    """The token-space path files its weight sums at EMIT positions; when the intersection capacity overflows there are none
+    (k_emit returns at once).  gwbp_scatter_tokens must then touch nothing (it used to be able to read through a stale
+    estart[]), the driver grows the workspace and the rerun equals a run with ample capacities."""
+    cfg, sc = scene_np("T1", n_views=3)
+    d = to_dev(sc, dev)
+    vms = syn.make_cameras(cfg, n_views=3).to(dev)
+    D, lh, lw = 256, 8, 12
+    lows = [torch.randn(lh, lw, D, generator=torch.Generator().manual_seed(60 + v)).to(dev) for v in range(3)]
+    args = (d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"], cfg.width, cfg.height)
+    kw = dict(feature_fn=lambda v: lows[v], dim=D, reduction="mean", upsample="nearest", return_partials=True, pipeline=pipeline)
+    small = gsbp_amd.Engine(cfg.n_gaussians, cfg.width, cfg.height, device=dev, isect_cap=3000, tight_binning=True)
+    a, Fa, da, st = gsbp_amd.create_feature_field(*args, **kw, engine=small)
+    assert small.isect_cap > 3000 and st["overflow"] == 0
+    b, Fb, db, _ = gsbp_amd.create_feature_field(*args, **kw)
+    assert rel_row_err(Fa.cpu().numpy(), Fb.cpu().numpy()) <= 1e-5
+    assert np.abs(da.cpu().numpy() - db.cpu().numpy()).max() <= 1e-5 * float(db.max())
+
+
 @pytest.mark.parametrize("D", [128, 256, 512])
 def test_create_feature_field_bilinear_matches_materialised(D, dev):
     """The driver with upsample="bilinear" (low-resolution maps handed over) against the driver fed with
