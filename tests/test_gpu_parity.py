@@ -766,6 +766,56 @@ def test_token_space_scatter_against_oracle(orc, dev, D):
         eng.blend_tokens(view, 13, 17)  # texels narrower than a tile
 
 
+def test_token_space_edge_cases(orc, dev):
+    """Token space at the edges the reference's tests would hold if it had any: no Gaussians; an image smaller than a tile with a
+    1 x 1 token map (every pixel one token: F[g, :] = d[g] * token); whole-screen splats whose tile rectangles span the image
+    (96 x 64 = 24 tiles each, more than one batch of 16 emit slots per Gaussian) over a 3 x 5 token map; every Gaussian culled."""
+    # N = 0
+    eng0 = gsbp_amd.Engine(0, 40, 24, device=dev)
+    z3, z4, z1 = torch.zeros(0, 3, device=dev), torch.zeros(0, 4, device=dev), torch.zeros(0, device=dev)
+    view0 = eng0.view(torch.eye(4), torch.tensor([[50.0, 0, 20], [0, 50.0, 12], [0, 0, 1]]), 40, 24)
+    eng0.project(view0, z3, z4, z3, z1)
+    eng0.bin_sort(view0)
+    eng0.blend_tokens(view0, 1, 2)
+    eng0.scatter_tokens(view0, torch.rand(1, 2, 256, device=dev), torch.zeros(0, 256, device=dev), torch.zeros(0, device=dev))
+    assert eng0.stats()["n_pairs"] == 0 and eng0.stats()["overflow"] == 0
+    g = torch.Generator().manual_seed(8)
+    vm = torch.eye(4)
+    for (W, H, lh, lw, n_big, n_small, D) in ((13, 9, 1, 1, 2, 20, 256), (96, 64, 3, 5, 6, 40, 512)):
+        n = n_big + n_small
+        K = torch.tensor([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]])
+        means = torch.cat([torch.tensor([[0.0, 0.0, 2.0 + 0.1 * i] for i in range(n_big)]),
+                           torch.rand(n_small, 3, generator=g) * torch.tensor([1.6, 1.0, 1.0]) + torch.tensor([-0.8, -0.5, 1.5])])
+        scales = torch.cat([torch.full((n_big, 3), 3.0), torch.full((n_small, 3), 0.05)])
+        quats = torch.randn(n, 4, generator=g)
+        opac = torch.cat([torch.full((n_big,), 0.05), torch.rand(n_small, generator=g)])
+        low = torch.randn(lh, lw, D, generator=g)
+        up = torch.nn.functional.interpolate(low.permute(2, 0, 1)[None], size=(H, W), mode="nearest")[0].permute(1, 2, 0)
+        assert gsbp_amd.Engine.token_geometry_ok(lh, lw, H, W)
+        eng = gsbp_amd.Engine(n, W, H, device=dev)
+        view = eng.view(vm, K, W, H)
+        eng.project(view, means.to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
+        eng.bin_sort(view)
+        eng.blend_tokens(view, lh, lw)
+        F, dd = torch.zeros(n, D, device=dev), torch.zeros(n, device=dev)
+        eng.scatter_tokens(view, low.to(dev), F, dd)
+        Fr, dr = np.zeros((n, D)), np.zeros(n)
+        info = orc.backproject_view(means.numpy(), quats.numpy(), scales.numpy(), opac.numpy(), vm.numpy(), K.numpy(), W, H,
+                                    np.ascontiguousarray(up.numpy()), Fr, dr)
+        st = eng.stats()
+        assert st["overflow"] == 0 and st["n_pairs"] == info["n_pairs"] > 0
+        assert rel_row_err(F.cpu().numpy(), Fr) <= TOL and rel_row_err(dd.cpu().numpy()[:, None], dr[:, None]) <= TOL
+        if lh == lw == 1:  # one token for the whole image: F[g, :] = d[g] * token
+            assert float((F - dd[:, None] * low.to(dev)[0, 0][None]).abs().max()) <= 1e-5 * float(dd.max()) * float(low.abs().max())
+    # every Gaussian behind the camera: nothing is touched
+    eng.project(view, (means * torch.tensor([1.0, 1.0, -1.0])).to(dev), quats.to(dev), scales.to(dev), opac.to(dev))
+    eng.bin_sort(view)
+    eng.blend_tokens(view, lh, lw)
+    F2, d2 = torch.full((n, D), 7.0, device=dev), torch.full((n,), 3.0, device=dev)
+    eng.scatter_tokens(view, low.to(dev), F2, d2)
+    assert eng.stats()["n_visible"] == 0 and bool((F2 == 7.0).all()) and bool((d2 == 3.0).all())
+
+
 def test_token_space_precondition_is_enforced_on_the_device(dev):
     """The C ABI's own guard: index maps that send a tile to more than 2 x 2 texels raise gwbp_stats.overflow bit 3 (the Python
     host never calls gwbp_blend_tokens with such maps; a foreign caller of the C ABI might)."""
