@@ -428,3 +428,21 @@ def test_cli_accepts_every_parameter_of_the_reference_main():
     assert r.returncode == 0, r.stderr[-800:]
     for flag in ("--feature-field-batch-count", "--run-feature-field-on-cpu", "--no-run-feature-field-on-cpu"):
         assert flag in r.stdout
+
+
+def test_token_geometry_rule_follows_the_exact_index_maps():
+    """Engine.token_geometry_ok decides (on the host, from PyTorch's own fp32 nearest rule) whether every 16 x 16 tile of the view
+    sees at most 2 x 2 texels of a low-resolution map -- the precondition of gwbp_blend_tokens.  The dino script's 64 x 64 tokens at
+    the garden scene's 1600 x 1060 qualify, the lseg script's 480 x 480 map does not; the rule is checked against a brute-force
+    walk over the index maps, including sizes where 16 * n_in <= n_out fails by one texel."""
+    import itertools
+    from gsbp_amd import Engine, nearest_index
+    assert Engine.token_geometry_ok(64, 64, 1060, 1600)
+    assert not Engine.token_geometry_ok(480, 480, 1060, 1600)
+    assert Engine.token_geometry_ok(1, 1, 9, 13) and Engine.token_geometry_ok(8, 12, 136, 200)
+    assert not Engine.token_geometry_ok(13, 17, 136, 200)
+    for n_in, n_out in itertools.product((1, 2, 3, 5, 8, 9, 12, 13, 33, 66, 67), (1, 15, 16, 17, 136, 200, 1060)):
+        m = nearest_index(n_in, n_out).tolist()
+        assert all(b >= a for a, b in zip(m, m[1:])) and m[-1] <= n_in - 1  # non-decreasing, inside the map
+        brute = all(m[min(t + 15, n_out - 1)] - m[t] <= 1 for t in range(0, n_out, 16))
+        assert Engine.token_geometry_ok(n_in, 1, n_out, 16) == brute, (n_in, n_out)
