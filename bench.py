@@ -495,8 +495,13 @@ def main():
         out["dist"] = dist_info
         out["exchange_ms"] = exchange_ms
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder,
-                                               args.cpu_views)
+            out["cpu_baseline"], Fc, dc, cpu_pairs = cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder,
+                                                                   args.cpu_views)
+            # The oracle's accumulators over those views are not thrown away: the PRODUCT runs the same views (its kernels on
+            # one stream) and must reproduce them row by row within the north_star's 1e-4 -- oracle evidence at the bench's own
+            # size on every bench line, outside the timed region.
+            out["oracle_check"] = oracle_check(gsbp_amd, eng, cfg, (means, quats, scales, opac), vms, K, pool, encoder, D, sf, sd,
+                                               token_grid, args.cpu_views, Fc, dc, cpu_pairs, dev)
         line = json.dumps(out)
     else:
         line = None
@@ -624,11 +629,58 @@ def cpu_baseline(cfg, syn, means, quats, scales, opac, vms, K, pool, D, encoder,
                                     feats[v % len(feats)], Fc, dc, nthreads=cores)
         t += time.perf_counter() - t0
         pairs += info["n_pairs"]
-    return {"value": pairs * D / t, "unit": "Gaussian-pixel-features/s", "cores": cores, "kind": "port",
-            "sample": f"{n_views} view(s) of {cfg.name} at full size (N={cfg.n_gaussians}, {cfg.width}x{cfg.height}, "
-                      f"D={D}), oracle/gwbp_oracle.c with OpenMP on the {cores} CPUs this container may use "
-                      f"(os.cpu_count() = {os.cpu_count()}), fp32 accumulators",
-            "seconds": t, "views_per_sec": n_views / t}
+    return ({"value": pairs * D / t, "unit": "Gaussian-pixel-features/s", "cores": cores, "kind": "port",
+             "sample": f"{n_views} view(s) of {cfg.name} at full size (N={cfg.n_gaussians}, {cfg.width}x{cfg.height}, "
+                       f"D={D}), oracle/gwbp_oracle.c with OpenMP on the {cores} CPUs this container may use "
+                       f"(os.cpu_count() = {os.cpu_count()}), fp32 accumulators",
+             "seconds": t, "views_per_sec": n_views / t}, Fc, dc, pairs)
+
+
+def oracle_check(gsbp_amd, eng, cfg, g, vms, K, pool, encoder, D, sf, sd, token_grid, n_views, Fc, dc, cpu_pairs, dev):
+    """The product against the CPU oracle at the bench's own size: the views the CPU baseline was timed on (cameras 0 .. n_views-1,
+    the pool's maps) through the product's kernels on one stream -- the encoder-fused, token-space or upsampling path the config
+    takes -- compared with the oracle's accumulators row by row (the oracle got the materialised upsampled / encoded maps, like
+    the reference).  fp32 sums of a few views on both sides: the north_star's 1e-4 relative per row."""
+    import torch
+    N, W, H = cfg.n_gaussians, cfg.width, cfg.height
+    F2 = torch.zeros(N, D, device=dev)
+    d2 = torch.zeros(N, device=dev)
+    accum = torch.zeros(32, dtype=torch.uint8, device=dev)
+    maps = pool[:(2 if cfg.lowres else n_views)]
+    eng.set_front_priority(False)
+    eng.set_narrow_scatter(D % 256 != 0)
+    for v in range(n_views):
+        view = eng.view(vms[v], K, W, H)
+        feats = maps[v % len(maps)]
+        eng.project(view, *g)
+        eng.bin_sort(view)
+        if encoder is not None and gsbp_amd.Engine.can_blend_scatter_encoded(feats, encoder):
+            eng.blend_scatter_encoded(view, feats, encoder, F2, d2)
+        elif encoder is not None:
+            eng.blend_weights(view)
+            eng.scatter(view, eng.encode_map(feats, encoder), F2, d2)
+        elif token_grid is not None:
+            eng.blend_tokens(view, *token_grid)
+            eng.scatter_tokens(view, feats, F2, d2)
+        elif cfg.upsample is None and gsbp_amd.Engine.can_blend_scatter(feats):
+            eng.blend_scatter(view, feats, F2, d2)
+        else:
+            eng.blend_weights(view)
+            eng.scatter(view, feats, F2, d2, upsample=cfg.upsample)
+        eng.accumulate_stats(accum)
+    st = gsbp_amd.Engine.decode_stats(accum)
+    Fr, dr = torch.from_numpy(Fc).to(dev), torch.from_numpy(dc).to(dev)
+    fn = Fr.double().norm(dim=1)
+    scale = torch.maximum(fn, 1e-6 * fn.max().clamp_min(1e-30))
+    err_f = float(((F2.double() - Fr.double()).norm(dim=1) / scale).max())
+    dscale = torch.maximum(dr.double(), 1e-6 * dr.double().max().clamp_min(1e-30))
+    err_d = float(((d2.double() - dr.double()).abs() / dscale).max())
+    ok = bool(err_f <= 1e-4 and err_d <= 1e-4 and st["overflow"] == 0 and int(st["n_pairs"]) == int(cpu_pairs))
+    # (the oracle's sums are unscaled: reduction="mean" scales are left out on both sides here, they are plain factors)
+    return {"ok": ok, "views": n_views, "F_max_rel_row_err": err_f, "d_max_rel_err": err_d,
+            "pairs_product": int(st["n_pairs"]), "pairs_oracle": int(cpu_pairs), "tolerance": 1e-4,
+            "method": "the CPU baseline's views through the product's kernels on one stream, every row of F and d against the "
+                      "oracle's accumulators (oracle/gwbp_oracle.c; parity unpinned: the oracle restates gsplat 1.4.0)"}
 
 
 if __name__ == "__main__":

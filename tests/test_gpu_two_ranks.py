@@ -132,3 +132,27 @@ def test_bench_refuses_more_ranks_than_gpus(dev):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode != 0 and f"--gpus {n}" in (r.stderr + r.stdout) and "GPU(s)" in (r.stderr + r.stdout)
+
+
+def test_bench_line_carries_roofline_cpu_baseline_and_an_oracle_check(dev):
+    """The default bench line (one rank, CPU baseline on): `roofline` and `cpu_baseline` as the contract asks, `checked` (second
+    pass through another kernel path) and -- round 6 -- `oracle_check`: the CPU baseline's own views through the product's kernels,
+    every row of F and d against the oracle's accumulators, pair counts equal.  C1 size here; the driver's C2 line carries the same
+    object at full size."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "8", "--warmup", "2",
+                        "--cpu-views", "2"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len([ln for ln in lines if ln.startswith('{"metric"')]) == 1 and lines[-1].startswith('{"metric"')
+    j = json.loads(lines[-1])
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1 and j["roofline"]["peak"] == 8000.0
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "2 view(s) of C1" in cb["sample"]
+    oc = j["oracle_check"]
+    assert oc["ok"] is True and oc["views"] == 2 and oc["pairs_product"] == oc["pairs_oracle"] > 0
+    assert oc["F_max_rel_row_err"] <= 1e-4 and oc["d_max_rel_err"] <= 1e-4
+    assert j["checked"]["ok"] is True and j["vs_baseline"] is None and j["dtype"] == "f32" and j["n_gpus"] == 1
