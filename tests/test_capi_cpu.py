@@ -39,6 +39,20 @@ def test_library_exports_nothing_but_the_declared_symbols():
     assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
 
 
+def test_header_is_plain_c():
+    """a C ABI -- the header a foreign binding (cgo, JNI, ctypes generators) would include must compile as C99 and
+    as C++ on its own, with no torch / HIP include behind it."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", HDR])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", HDR])
+    code = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)  # (the comments may NAME torch and HIP types)
+    assert set(re.findall(r"#include\s*<([^>]+)>", code)) == {"stddef.h", "stdint.h"}
+    assert not re.search(r"\b(at::|torch|hipStream_t|hipError_t)\b", code)
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.View) == 16 * 4 + 9 * 4 + 2 * 4 + 4 * 4
     assert C.sizeof(_lib.Caps) == 8 * 3 + 4 * 4
