@@ -30,7 +30,8 @@ constexpr int kTokCh = 256;       // channels per wave pass: one float4 per lane
 constexpr int kTokPerWave = 16;   // Gaussians (consecutive in depth order) per wave
 constexpr int kTokWaves = 4;
 constexpr int kTokGroup = kTokPerWave * kTokWaves; // Gaussians per workgroup
-constexpr int kTokMaxTiles = 1024;                 // tile columns / rows of the largest view the token path takes (16 384 px)
+constexpr int kTokMaxTiles = 256;                  // tile columns / rows of the largest view the token path takes (4096 px): 2 KB of
+                                                   // LDS tables, so that four workgroups with their 36 KB token windows share a CU
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -85,6 +86,24 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
         s_tc0[i] = A.xmap[min(i * kTile, A.W - 1)];
     for (int i = threadIdx.x; i < tile_h; i += 64 * kTokWaves)
         s_tr0[i] = A.ymap[min(i * kTile, A.H - 1)];
+    // TILE_ORDER: the 3 x 3 token rows below / right of the first token of the workgroup's first tile, staged in LDS once: the home
+    // Gaussians of that tile (rectangles of up to 2 x 2 tiles reach at most three token columns and rows) read their token rows
+    // from there instead of from L2 -- in tile order the kernel is bound by the L2 -> CU traffic of those rows (12 TB/s)
+    int win_c = 0, win_r = 0;
+    if constexpr (TILE_ORDER) {
+        extern __shared__ __attribute__((aligned(16))) float s_win[];
+        const u32 t0 = A.sorted_tiles[blockIdx.x * (u32)(64 * kTokWaves)];
+        win_c = s_tc0[0], win_r = s_tr0[0]; // (placeholders: the tables are being written; set behind the barrier)
+        __syncthreads();
+        win_c = s_tc0[min((int)(t0 % (u32)tile_w), tile_w - 1)], win_r = s_tr0[min((int)(t0 / (u32)tile_w), tile_h - 1)];
+        const int tc_max = A.xmap[A.W - 1], tr_max = A.ymap[A.H - 1];
+        const int per_row = A.D / 4; // float4 per token row
+        for (int i = threadIdx.x; i < 9 * per_row; i += 64 * kTokWaves) {
+            const int w9 = i / per_row, c4 = i - w9 * per_row;
+            const long long o = (long long)min(win_r + w9 / 3, tr_max) * A.ts_y + (long long)min(win_c + w9 % 3, tc_max) * A.ts_x;
+            reinterpret_cast<f4 *>(s_win)[i] = reinterpret_cast<const f4 *>(A.tokens + o)[c4];
+        }
+    }
     __syncthreads();
     const int lane = (int)(threadIdx.x & 63u), wave = (int)uniform(threadIdx.x >> 6);
     // WHICH Gaussians a wave takes.  Product: 16 consecutive Gaussians of the depth order (= the emit order; screen positions at
@@ -188,9 +207,23 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                             w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(om), l));
                             const long long o = ((long long)__builtin_amdgcn_readlane(thi, l) << 32) |
                                                 (long long)(u32)__builtin_amdgcn_readlane(tlo, l);
+                            bool hit = false;
+                            if constexpr (TILE_ORDER) { // (wave-uniform) inside the workgroup's LDS window?
+                                extern __shared__ __attribute__((aligned(16))) float s_win[];
+                                const int er = __builtin_amdgcn_readlane(tr, l) - win_r, ec = __builtin_amdgcn_readlane(tc, l) - win_c;
+                                hit = (u32)er < 3u && (u32)ec < 3u;
+                                if (hit) {
+                                    const float *wrow = s_win + (size_t)(er * 3 + ec) * A.D + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
 #pragma unroll
-                            for (int c = 0; c < NC; ++c)
-                                t[u][c] = *reinterpret_cast<const f4 *>(tbase + o + c * kTokCh);
+                                    for (int c = 0; c < NC; ++c)
+                                        t[u][c] = *reinterpret_cast<const f4 *>(wrow + c * kTokCh);
+                                }
+                            }
+                            if (!hit) {
+#pragma unroll
+                                for (int c = 0; c < NC; ++c)
+                                    t[u][c] = *reinterpret_cast<const f4 *>(tbase + o + c * kTokCh);
+                            }
                         }
                     }
 #pragma unroll
@@ -259,22 +292,32 @@ int launch_token_apply(const Layout &L, const Ws &W, const ViewDev &V, const flo
     const int nc = D % (4 * kTokCh) == 0 ? 4 : D % (2 * kTokCh) == 0 ? 2 : 1;
     const int fin = sort_passes(V.tile_w * V.tile_h) & 1; // where the tile sort left its result
     A.sorted_tiles = W.keys[fin], A.sorted_gids = W.vals[fin];
-#ifdef GWBP_TOKEN_TILE_ORDER // (measured: see k_token_apply)
-    constexpr bool kTileOrder = true;
-    const int64_t blocks = (L.isect_cap + 64 * kTokWaves - 1) / (64 * kTokWaves);
+    // the tile-order walk with the workgroup's 3 x 3 token window in LDS (9 D floats: D <= 1024 within the default 48 KB... 1280);
+    // wider maps, and -DGWBP_TOKEN_DEPTH_ORDER builds (same-box A/B), walk the Gaussians in depth order and read every row from L2
+    const size_t lds = (size_t)9 * D * sizeof(float);
+#ifndef GWBP_TOKEN_DEPTH_ORDER
+    const bool tile_order = lds <= 48 * 1024;
 #else
-    constexpr bool kTileOrder = false;
-    const int64_t blocks = (L.n + kTokGroup - 1) / kTokGroup;
+    const bool tile_order = false;
 #endif
+    const int64_t blocks = tile_order ? (L.isect_cap + 64 * kTokWaves - 1) / (64 * kTokWaves) : (L.n + kTokGroup - 1) / kTokGroup;
     if (blocks > 0x7FFFFFFFll)
         return set_error(GWBP_EINVAL, "gwbp_scatter_tokens: grid too large");
     const dim3 grid((unsigned)blocks), block(64 * kTokWaves);
+#define GWBP_TOK_LAUNCH(NCV)                                                                                                   \
+    do {                                                                                                                       \
+        if (tile_order)                                                                                                        \
+            hipLaunchKernelGGL((k_token_apply<NCV, true>), grid, block, lds, s, A);                                            \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((k_token_apply<NCV, false>), grid, block, 0, s, A);                                             \
+    } while (0)
     if (nc == 4)
-        hipLaunchKernelGGL((k_token_apply<4, kTileOrder>), grid, block, 0, s, A);
+        GWBP_TOK_LAUNCH(4);
     else if (nc == 2)
-        hipLaunchKernelGGL((k_token_apply<2, kTileOrder>), grid, block, 0, s, A);
+        GWBP_TOK_LAUNCH(2);
     else
-        hipLaunchKernelGGL((k_token_apply<1, kTileOrder>), grid, block, 0, s, A);
+        GWBP_TOK_LAUNCH(1);
+#undef GWBP_TOK_LAUNCH
     return check_hip(hipGetLastError(), "token_apply launch");
 }
 
