@@ -151,79 +151,47 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
         const u32 cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k), es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
         return (u32)sl < cnt ? A.omega[(size_t)(es + (u32)sl) * 4 + quad] : 0.f;
     };
-    float om_next = first_batch(__ffsll((long long)rest) - 1);
-    while (rest != 0ull) {
-        const int k = __ffsll((long long)rest) - 1;
-        rest &= rest - 1;
-        const float om_first = om_next;
-        if (rest != 0ull)
-            om_next = first_batch(__ffsll((long long)rest) - 1); // lands under this Gaussian's row traffic
-        const u32 gid = (u32)__builtin_amdgcn_readlane((int)m_gid, k), cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k);
-        const u32 es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
+    // the token rows of one Gaussian's weight sums, times the sums, into acc (entry order = emit order: the result does not depend on
+    // which walk reaches the Gaussian); on_first() runs in front of the first token read (wave-uniform).  Returns whether any sum
+    // of the Gaussian is non-zero
+    auto accumulate = [&](int k, float om_first, int pass, f4 (&acc)[NC], float &dsum, auto &&on_first) -> bool {
+        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k), es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
         const u32 rx = (u32)__builtin_amdgcn_readlane((int)m_rx, k), ry = (u32)__builtin_amdgcn_readlane((int)m_ry, k);
         const u32 x0 = rx & 0xFFFFu, rw = (rx >> 16) - x0, y0 = ry & 0xFFFFu;
-        if (cnt <= 16u && __ballot(om_first != 0.f) == 0ull)
-            continue; // visible, binned, but no pixel with weight: F and d keep their values (nothing is read or written)
-        float dsum = 0.f;
-        for (int pass = 0; pass < n_pass; ++pass) {
-            float *frow = A.F + (size_t)gid * (size_t)A.D + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
-            const float *tbase = A.tokens + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
-            f4 acc[NC], fold[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                acc[c] = f4{0.f, 0.f, 0.f, 0.f};
-            bool any = false; // wave-uniform: some sum of this Gaussian is non-zero
-            for (u32 s0 = 0; s0 < cnt; s0 += 16u) {
-                const u32 slot = s0 + (u32)sl;
-                const float om = s0 == 0u ? om_first : (slot < cnt ? A.omega[(size_t)(es + slot) * 4 + quad] : 0.f);
-                const u64 nz = __ballot(om != 0.f);
-                if (nz == 0ull)
-                    continue;
-                if (!any) { // first weight of this Gaussian: start the row's read now, it lands under the token reads
-                    any = true;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-                        fold[c] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(frow + c * kTokCh));
-                }
-                if (pass == 0)
-                    dsum += om;
-                // the token under this lane's (tile, quadrant): first token of the tile + (qx, qy); only dereferenced where om != 0,
-                // i.e. where the blend found a pixel of that token
-                const u32 ty = y0 + slot / rw, tx = x0 + slot % rw;
-                const int tc = s_tc0[min(tx, (u32)tile_w - 1u)] + (quad & 1);
-                const int tr = s_tr0[min(ty, (u32)tile_h - 1u)] + (quad >> 1);
-                const long long toff = (long long)tr * A.ts_y + (long long)tc * A.ts_x;
-                const int tlo = (int)(u32)toff, thi = (int)(toff >> 32);
-                u64 todo = nz;
-                while (todo != 0ull) { // two entries' rows (2 x NC loads) in flight
+        const float *tbase = A.tokens + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
+        // one batch of 16 emit slots x 4 quadrants, one sum per lane
+        auto batch = [&](float om, u32 slot, u64 nz) {
+            if (pass == 0)
+                dsum += om;
+            // the token under this lane's (tile, quadrant): first token of the tile + (qx, qy); only dereferenced where om != 0,
+            // i.e. where the blend found a pixel of that token
+            const u32 ty = y0 + slot / rw, tx = x0 + slot % rw;
+            const int tc = s_tc0[min(tx, (u32)tile_w - 1u)] + (quad & 1);
+            const int tr = s_tr0[min(ty, (u32)tile_h - 1u)] + (quad >> 1);
+            u64 miss = nz;
+            if constexpr (TILE_ORDER) {
+                // the entries whose token lies in the workgroup's LDS window first, in a loop of their own without a global load
+                // (one loop with both sources has to wait for EVERYTHING in flight at the join, the next Gaussian's row included)
+                extern __shared__ __attribute__((aligned(16))) float s_win[];
+                const int er = tr - win_r, ec = tc - win_c;
+                const bool inside = (u32)er < 3u && (u32)ec < 3u;
+                u64 hits = nz & __ballot(inside);
+                miss = nz & ~hits;
+                const int woff = (er * 3 + ec) * A.D + pass * (kTokCh * NC); // (floats; only read from lanes inside)
+                while (hits != 0ull) { // two entries' rows in flight
                     f4 t[2][NC];
                     float w[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         w[u] = 0.f;
-                        if (todo != 0ull) { // wave-uniform
-                            const int l = __ffsll((long long)todo) - 1;
-                            todo &= todo - 1;
+                        if (hits != 0ull) { // wave-uniform
+                            const int l = __ffsll((long long)hits) - 1;
+                            hits &= hits - 1;
                             w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(om), l));
-                            const long long o = ((long long)__builtin_amdgcn_readlane(thi, l) << 32) |
-                                                (long long)(u32)__builtin_amdgcn_readlane(tlo, l);
-                            bool hit = false;
-                            if constexpr (TILE_ORDER) { // (wave-uniform) inside the workgroup's LDS window?
-                                extern __shared__ __attribute__((aligned(16))) float s_win[];
-                                const int er = __builtin_amdgcn_readlane(tr, l) - win_r, ec = __builtin_amdgcn_readlane(tc, l) - win_c;
-                                hit = (u32)er < 3u && (u32)ec < 3u;
-                                if (hit) {
-                                    const float *wrow = s_win + (size_t)(er * 3 + ec) * A.D + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
+                            const float *wrow = s_win + __builtin_amdgcn_readlane(woff, l) + lane * 4;
 #pragma unroll
-                                    for (int c = 0; c < NC; ++c)
-                                        t[u][c] = *reinterpret_cast<const f4 *>(wrow + c * kTokCh);
-                                }
-                            }
-                            if (!hit) {
-#pragma unroll
-                                for (int c = 0; c < NC; ++c)
-                                    t[u][c] = *reinterpret_cast<const f4 *>(tbase + o + c * kTokCh);
-                            }
+                            for (int c = 0; c < NC; ++c)
+                                t[u][c] = *reinterpret_cast<const f4 *>(wrow + c * kTokCh);
                         }
                     }
 #pragma unroll
@@ -239,6 +207,176 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                         }
                 }
             }
+            if (miss == 0ull)
+                return;
+            const long long toff = (long long)tr * A.ts_y + (long long)tc * A.ts_x;
+            const int tlo = (int)(u32)toff, thi = (int)(toff >> 32);
+            while (miss != 0ull) { // two entries' rows (2 x NC loads) in flight
+                f4 t[2][NC];
+                float w[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    w[u] = 0.f;
+                    if (miss != 0ull) { // wave-uniform
+                        const int l = __ffsll((long long)miss) - 1;
+                        miss &= miss - 1;
+                        w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(om), l));
+                        const long long o = ((long long)__builtin_amdgcn_readlane(thi, l) << 32) |
+                                            (long long)(u32)__builtin_amdgcn_readlane(tlo, l);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                            t[u][c] = *reinterpret_cast<const f4 *>(tbase + o + c * kTokCh);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (w[u] != 0.f) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            acc[c].x = __builtin_fmaf(w[u], t[u][c].x, acc[c].x);
+                            acc[c].y = __builtin_fmaf(w[u], t[u][c].y, acc[c].y);
+                            acc[c].z = __builtin_fmaf(w[u], t[u][c].z, acc[c].z);
+                            acc[c].w = __builtin_fmaf(w[u], t[u][c].w, acc[c].w);
+                        }
+                    }
+            }
+        };
+        // the first batch's sums are in registers already; the loop over further batches (rectangles of more than 16 tiles) is
+        // a loop of its own, so that the common case has no load of sums in front of its token reads
+        bool any = false;
+        {
+            const u64 nz = __ballot(om_first != 0.f);
+            if (nz != 0ull) {
+                any = true;
+                on_first();
+                batch(om_first, (u32)sl, nz);
+            }
+        }
+        for (u32 s0 = 16u; s0 < cnt; s0 += 16u) {
+            const u32 slot = s0 + (u32)sl;
+            const float om = slot < cnt ? A.omega[(size_t)(es + slot) * 4 + quad] : 0.f;
+            const u64 nz = __ballot(om != 0.f);
+            if (nz == 0ull)
+                continue;
+            if (!any) {
+                any = true;
+                on_first();
+            }
+            batch(om, slot, nz);
+        }
+        return any;
+    };
+    auto pop = [&]() -> int { // the wave's next Gaussian (a lane index), -1 behind the last
+        if (rest == 0ull)
+            return -1;
+        const int k = __ffsll((long long)rest) - 1;
+        rest &= rest - 1;
+        return k;
+    };
+#ifndef GWBP_TOKEN_NO_PREFETCH
+    if (n_pass == 1) { // (wave-uniform) all channels in one pass, D = 256 NC
+        // Which of the wave's Gaussians have weight at all, found lane-parallel: lane j looks through the (up to 16) first sums of
+        // ITS Gaussian, 16 independent loads in flight.  The walk below then only visits Gaussians whose row it will write, which is
+        // what lets it request the NEXT Gaussian's row and sums unconditionally, a Gaussian ahead.
+        {
+            const u32 last = m_cnt ? min(m_cnt, 16u) - 1u : 0u;
+            const float4 *om4 = reinterpret_cast<const float4 *>(A.omega) + m_es;
+            float4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                v[i] = om4[min((u32)i, last)];
+            u32 bits = 0u; // (OR of the bit patterns without the sign: != 0 exactly when some sum is not +-0; no short circuit,
+                           // which would put a wait and a branch behind every load)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                bits |= (__float_as_uint(v[i].x) | __float_as_uint(v[i].y) | __float_as_uint(v[i].z) | __float_as_uint(v[i].w)) &
+                        0x7FFFFFFFu;
+            rest = __ballot(m_cnt != 0u && (m_cnt > 16u || bits != 0u));
+            if (rest == 0ull)
+                return;
+        }
+        // (sums, row, d) of a Gaussian: requests without conditions -- the waits in the walk are counted ones (vmcnt retires in
+        // order; a wait in front of a path-dependent number of younger loads would have to drain them all)
+        const float *dsrc = A.d ? A.d : A.omega;
+        auto request = [&](int k, float &om, f4 (&fold)[NC], float &dv) {
+            const u32 cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k), es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
+            const u32 gid = (u32)__builtin_amdgcn_readlane((int)m_gid, k);
+            om = A.omega[(size_t)(es + min((u32)sl, cnt - 1u)) * 4 + quad];
+            const float *row = A.F + (size_t)gid * (size_t)A.D + (size_t)lane * 4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                fold[c] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(row + c * kTokCh));
+            dv = dsrc[A.d ? gid : 0u];
+        };
+        // one Gaussian: request the next one's operands into the OTHER register set, work on this one, store; returns the next
+        auto step = [&](int kc, float om_c, f4 (&fold_c)[NC], float d_c, float &om_n, f4 (&fold_n)[NC], float &d_n) -> int {
+            const int kn = pop();
+            request(kn >= 0 ? kn : kc, om_n, fold_n, d_n);
+            const u32 gid = (u32)__builtin_amdgcn_readlane((int)m_gid, kc), cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, kc);
+            f4 acc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                acc[c] = f4{0.f, 0.f, 0.f, 0.f};
+            float dsum = 0.f;
+            const bool any = accumulate(kc, (u32)sl < cnt ? om_c : 0.f, 0, acc, dsum, [] {});
+            if (any) { // (a Gaussian of more than 16 slots may still be without weight: nothing is written then)
+                float *frow = A.F + (size_t)gid * (size_t)A.D + (size_t)lane * 4;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    f4 r = fold_c[c];
+                    r.x = __builtin_fmaf(A.scale_f, acc[c].x, r.x);
+                    r.y = __builtin_fmaf(A.scale_f, acc[c].y, r.y);
+                    r.z = __builtin_fmaf(A.scale_f, acc[c].z, r.z);
+                    r.w = __builtin_fmaf(A.scale_f, acc[c].w, r.w);
+                    __builtin_nontemporal_store(r, reinterpret_cast<f4 *>(frow + c * kTokCh));
+                }
+                if (A.d) { // the wave owns d[gid] as well: plain read-modify-write
+                    const float tot = wave_sum(dsum);
+                    if (lane == 0)
+                        A.d[gid] = __builtin_fmaf(A.scale_d, tot, d_c);
+                }
+            }
+            return kn;
+        };
+        int kc = pop();
+        float om_a, om_b, d_a, d_b;
+        f4 fold_a[NC], fold_b[NC];
+        request(kc, om_a, fold_a, d_a);
+        for (;;) { // the two register sets swap roles: no copy (a copy would wait for the request it has just made)
+            kc = step(kc, om_a, fold_a, d_a, om_b, fold_b, d_b);
+            if (kc < 0)
+                break;
+            kc = step(kc, om_b, fold_b, d_b, om_a, fold_a, d_a);
+            if (kc < 0)
+                break;
+        }
+        return;
+    }
+#endif
+    // several passes over the channels (D = 768, 1280 ...): the sums of the next Gaussian are requested a Gaussian ahead, the row
+    // when the first weight is seen
+    float om_next = first_batch(__ffsll((long long)rest) - 1);
+    while (rest != 0ull) {
+        const int k = pop();
+        const float om_first = om_next;
+        if (rest != 0ull)
+            om_next = first_batch(__ffsll((long long)rest) - 1); // lands under this Gaussian's row traffic
+        const u32 gid = (u32)__builtin_amdgcn_readlane((int)m_gid, k), cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k);
+        if (cnt <= 16u && __ballot(om_first != 0.f) == 0ull)
+            continue; // visible, binned, but no pixel with weight: F and d keep their values (nothing is read or written)
+        float dsum = 0.f;
+        for (int pass = 0; pass < n_pass; ++pass) {
+            float *frow = A.F + (size_t)gid * (size_t)A.D + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
+            f4 acc[NC], fold[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                acc[c] = f4{0.f, 0.f, 0.f, 0.f};
+            const bool any = accumulate(k, om_first, pass, acc, dsum, [&] {
+            // first weight of this Gaussian: start the row's read now, it lands under the token reads
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    fold[c] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(frow + c * kTokCh));
+            });
             if (!any)
                 break;
 #pragma unroll
