@@ -15,13 +15,22 @@
 // HBM traffic per view: 8 B x D per Gaussian that receives weight (C2 geometry, D = 1024: 0.53 M rows -> 4.4 GB) + the 16-B sums
 // (0.06 GB); the token rows (about five 4-KB rows per touched Gaussian) come from L2 / Infinity Cache.
 //
-// Work map: one wave walks 16 consecutive Gaussians of the depth order (= the emit order: their sums are contiguous), one Gaussian at
-// a time over ALL its channels (up to four 256-channel chunks side by side), with the next Gaussian's sums requested a Gaussian
-// ahead.  (First version, measured at 2.17 ms per C2-geometry view at D = 1024: one (Gaussian, 256-channel chunk) per wave
-// iteration with the chunk tied to the XCD so that each L2 kept one 4 MB slice of the token map -- 3.4 M short dependent chains.
-// The same XCD-local channel groups in the one-wave-per-Gaussian kernel -- one / two chunks per wave, the rest of the channels on
-// the other XCD classes -- measured on one box beside the all-channels form: alone 1.55-1.66 / 1.32-1.35 against 1.25-1.27 ms, in
-// the pipeline 2.26-2.36 / 1.97 against 1.91: that L2 locality does not pay for the 4x / 2x number of dependent chains.)
+// Work map (k_token_apply<NC, true>, the product for D <= 1280): a workgroup of four waves takes 256 consecutive entries of the
+// (tile, depth)-sorted intersection list and works on the Gaussians whose HOME tile -- first tile of their rectangle, emit slot 0 --
+// is the entry's tile: every Gaussian exactly once, neighbours on the screen back to back.  The 3 x 3 token rows under the first
+// entry's tile are staged in LDS once (9 D floats); a Gaussian's rectangle of up to 2 x 2 tiles reaches at most three token columns
+// and rows, so almost every token read is an LDS read.  A wave first finds, lane-parallel, which of its Gaussians carry weight at
+// all, then walks those with two register sets: the NEXT Gaussian's F row, first 16 sums and d are requested (unconditionally, so
+// that the waits are counted ones) before the current one is multiplied out and stored -- a row's read, its write and the next
+// row's read are all in flight together.
+//
+// Measured per C2-geometry view at D = 1024, alone / in the pipeline, same box each step (profiles/r6_token_*.txt, DESIGN.md
+// section 9): first version -- one (Gaussian, 256-channel chunk) per wave iteration, chunk tied to the XCD -- 2.17 ms; one wave
+// per Gaussian over all channels in depth order 1.27 / 1.85; tile order + LDS window 1.07 / 1.73; + the request one Gaussian
+// ahead 0.87 / 1.42 (4.45 GB of 4-KB rows read and written at 5.1 TB/s).  Depth order (k_token_apply<NC, false>) stays for
+// maps too wide for the window and as the -DGWBP_TOKEN_DEPTH_ORDER A/B build; -DGWBP_TOKEN_NO_PREFETCH builds the walk without
+// the second register set.  Tried and dropped: XCD-local channel groups (1.32-1.66 alone), tile order without the window (no gain:
+// the L2 gathers did not bind, the per-Gaussian latency chain did), a 2 x 2 register window, channel-group waves.
 #include "gwbp_dev.h"
 
 namespace gwbp {
@@ -62,7 +71,7 @@ struct TokenApplyArgs {
 
 // One wave = one Gaussian at a time, ALL its channels: NC chunks of 256 channels side by side (NC x float4 per lane; D = 1024:
 // NC = 4, one pass), so the Gaussian's weight sums are read and decoded once and every token row read / F row read-modify-write
-// of the Gaussian is in flight together.  The sums of the NEXT Gaussian are requested before this one is worked on.
+// of the Gaussian is in flight together.  The operands of the NEXT Gaussian are requested before this one is worked on.
 template <int NC, bool TILE_ORDER>
 __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A)
 {
@@ -106,14 +115,10 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
     }
     __syncthreads();
     const int lane = (int)(threadIdx.x & 63u), wave = (int)uniform(threadIdx.x >> 6);
-    // WHICH Gaussians a wave takes.  Product: 16 consecutive Gaussians of the depth order (= the emit order; screen positions at
-    // random, so their token rows are gathered from all over the 16 MB map: L2 hit rate 0.52, the rest from the Infinity Cache).
-    // TILE_ORDER (-DGWBP_TOKEN_TILE_ORDER, built to test whether those gathers bind): the wave takes 64 consecutive entries of
-    // the (tile, depth)-sorted intersection list and works on the Gaussians whose HOME tile -- the first tile of their rectangle,
-    // emit slot 0 -- is the entry's tile: every Gaussian exactly once, neighbours on the screen back to back, consecutive
-    // Gaussians read the SAME few token rows.  Measured on one box (DINO64): alone 1.266 against 1.285 ms, beside two fronts 1.86
-    // against 1.83 -- the gathers do not bind; what does is the latency chain of one F row read-modify-write per Gaussian and
-    // wave (4.45 GB of random 4-KB rows at 3.5 TB/s, one row in flight per wave).
+    // WHICH Gaussians a wave takes.  TILE_ORDER: 64 consecutive entries of the (tile, depth)-sorted intersection list, of which the
+    // wave works on the Gaussians whose HOME tile (first tile of the rectangle, emit slot 0) is the entry's tile -- every Gaussian
+    // exactly once, consecutive Gaussians read the SAME few token rows (the LDS window).  Otherwise: 16 consecutive Gaussians of
+    // the depth order (= the emit order; screen positions at random, token rows gathered from all over the map through L2).
     u32 m_gid = 0, m_cnt = 0, m_es = 0, m_rx = 0, m_ry = 0;
     if constexpr (TILE_ORDER) {
         const u32 n_isect = A.ctr->n_isect;

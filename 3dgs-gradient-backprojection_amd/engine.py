@@ -286,6 +286,7 @@ class Engine:
 
     # ---- token space: the dino variant's nearest-upsampled patch-token map (backproject.py:242-249) ------------------
     TOKEN_CHUNK = 256  # gwbp_scatter_tokens walks the channels in chunks of 256 (one float4 per lane)
+    TOKEN_MAX_VIEW = 4096  # ... and keeps per-tile-column / -row tables of 256 entries in LDS (token.hip kTokMaxTiles)
 
     _TOKEN_GEOMETRY: Dict[Tuple[int, int, int, int], bool] = {}
 
@@ -309,8 +310,11 @@ class Engine:
     @classmethod
     def can_scatter_tokens(cls, tokens: torch.Tensor, height: int, width: int) -> bool:
         """Low-resolution maps the token-space path takes: [h, w, D] float32 on the device, D % 256 == 0, channel-contiguous
-        16-B aligned rows, and texels at least a tile wide and high (token_geometry_ok)."""
+        16-B aligned rows, texels at least a tile wide and high (token_geometry_ok), views of at most 4096 x 4096 pixels.
+        Anything else goes through blend_weights + scatter(upsample="nearest")."""
         if tokens.dim() != 3 or not tokens.is_cuda or tokens.dtype != torch.float32:
+            return False
+        if max(int(height), int(width)) > cls.TOKEN_MAX_VIEW:
             return False
         sy, sx, sc = tokens.stride()
         D = tokens.shape[2]
@@ -340,7 +344,8 @@ class Engine:
             raise GwbpError("scatter_tokens needs blend_tokens(view, h, w) of the same view and map size first")
         if not self.can_scatter_tokens(tokens, view.height, view.width):
             raise GwbpError(f"scatter_tokens: [h,w,D] float32 map with D % 256 == 0, channel-contiguous 16-B aligned rows and texels "
-                            f"of at least a tile required, got {tuple(tokens.shape)} strides {tuple(tokens.stride())}")
+                            f"of at least a tile at a view of at most {self.TOKEN_MAX_VIEW} x {self.TOKEN_MAX_VIEW} pixels required, got "
+                            f"{tuple(tokens.shape)} strides {tuple(tokens.stride())} at {view.width} x {view.height}")
         D = tokens.shape[2]
         self._check_acc(F, d, D)
         ymap, xmap = self.nearest_maps(tokens.shape[0], tokens.shape[1], view.height, view.width)

@@ -481,9 +481,10 @@ def main():
                          # third ceiling, the one the 256-channel kernel's loop actually runs into:
                          # every (pair, channel) product reads 4 B of the LDS slab; MI355X_MICROARCH.md: ~150 TB/s
                          # aggregate for ds_read_b64/b128 with every CU streaming
-                         "lds_read_GBs": pairs_view * D * 4.0 / (t_scatter * 1e-3) / 1e9,
+                         # (token space multiplies per (record, token), not per pixel: no such product count to quote)
+                         "lds_read_GBs": None if token_grid is not None else pairs_view * D * 4.0 / (t_scatter * 1e-3) / 1e9,
                          "lds_peak_GBs": 150000.0,
-                         "lds_frac": pairs_view * D * 4.0 / (t_scatter * 1e-3) / 1e9 / 150000.0,
+                         "lds_frac": None if token_grid is not None else pairs_view * D * 4.0 / (t_scatter * 1e-3) / 1e9 / 150000.0,
                          # fourth ceiling, the one that binds together with the LDS time: vector instruction issue.  One
                          # wave-instruction per SIMD per 4 cycles; SQ_INSTS_VALU of the same kernel from the committed PMC
                          # pass (like `traffic`), SIMD-cycles = CUs x 4 x 2.4 GHz x this run's launch time

@@ -830,6 +830,33 @@ def test_token_space_precondition_is_enforced_on_the_device(dev):
     assert eng.stats()["overflow"] & 8
 
 
+def test_token_space_takes_views_up_to_4096_pixels_and_says_so(dev):
+    """gwbp_scatter_tokens keeps 256-entry tile-column / -row tables in LDS: a 4112-pixel-wide view is refused with
+    GWBP_EUNSUPPORTED by the C ABI (not run wrongly), Engine.can_scatter_tokens sends such a view to scatter(upsample="nearest")."""
+    import ctypes as C
+    from gsbp_amd._lib import ptr
+    W, H, D = 4112, 32, 256
+    tokens = torch.rand(1, 4, D, device=dev)
+    assert gsbp_amd.Engine.can_scatter_tokens(tokens, 32, 4096)
+    assert not gsbp_amd.Engine.can_scatter_tokens(tokens, H, W)
+    eng = gsbp_amd.Engine(4, W, H, device=dev)
+    K = torch.tensor([[3000.0, 0, W / 2], [0, 3000.0, H / 2], [0, 0, 1]])
+    view = eng.view(torch.eye(4), K, W, H)
+    means = torch.tensor([[0.0, 0, 4], [0.5, 0, 4], [-0.5, 0, 4], [0.2, 0, 5]], device=dev)
+    quats = torch.tensor([[1.0, 0, 0, 0]] * 4, device=dev)
+    eng.project(view, means, quats, torch.full((4, 3), 0.05, device=dev), torch.full((4,), 0.8, device=dev))
+    eng.bin_sort(view)
+    eng.blend_tokens(view, 1, 4)
+    F, d = torch.zeros(4, D, device=dev), torch.zeros(4, device=dev)
+    with pytest.raises(gsbp_amd.GwbpError, match="4096"):
+        eng.scatter_tokens(view, tokens, F, d)
+    ymap, xmap = eng.nearest_maps(1, 4, H, W)
+    with pytest.raises(gsbp_amd.GwbpError, match="tile columns"):
+        eng._call("gwbp_scatter_tokens", *eng._args(), C.byref(view), ptr(tokens), C.c_int64(4 * D), C.c_int64(D), D, ptr(ymap),
+                  ptr(xmap), C.c_float(1.0), C.c_float(1.0), ptr(F), ptr(d), eng._stream())
+    assert float(F.abs().sum()) == 0.0
+
+
 def test_token_space_non_finite_token_reaches_exactly_its_gaussians(orc, dev):
     """A NaN token (backproject.py:239-241 can produce one) must reach exactly the Gaussians that have weight inside it."""
     cfg, sc = scene_np("T1")

@@ -1,6 +1,6 @@
 """Randomised parity fuzz (GPU + oracle): many small random scenes, image sizes, channel counts, map layouts and both
 D % 256 == 0 scatter kernels against the CPU oracle.  Not part of the test suite (minutes of run time).
-  python tools/fuzz_parity.py [n_cases] [seed0]"""
+  python tools/fuzz_parity.py [n_cases] [seed0] [tokens]     ("tokens": every case through the token-space kernels)"""
 import math
 import sys
 import time
@@ -16,6 +16,7 @@ from util import rel_row_err  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+only_tokens = len(sys.argv) > 3 and sys.argv[3] == "tokens"  # every case a nearest-upsampled coarse map with D % 256 == 0
 dev = torch.device("cuda:0")
 orc.build()
 DIMS = [1, 3, 4, 7, 8, 12, 16, 17, 32, 40, 64, 65, 100, 128, 130, 256, 384, 512, 768, 1024]
@@ -32,6 +33,9 @@ for case in range(n_cases):
     n = int(rng.integers(1, 4000)) if rng.random() < 0.9 else int(rng.integers(4000, 30000))  # (depth-sort variants)
     W, H = int(rng.integers(1, 260)), int(rng.integers(1, 200))
     D = int(rng.choice(DIMS))
+    if only_tokens:
+        D = int(rng.choice([256, 256, 512, 768, 1024, 1280, 1536]))
+        W, H = int(rng.integers(16, 400)), int(rng.integers(16, 300))
     s0 = float(10 ** rng.uniform(-2.6, -0.3))
     g = torch.Generator().manual_seed(seed0 + case)
     means = (torch.rand(n, 3, generator=g) * 2 - 1) * float(rng.uniform(0.2, 1.5))
@@ -49,6 +53,8 @@ for case in range(n_cases):
     f = float(rng.uniform(0.5, 2.0)) * max(W, H)
     K = torch.tensor([[f, 0, W / 2 + float(rng.uniform(-3, 3))], [0, f * float(rng.uniform(0.8, 1.2)), H / 2], [0, 0, 1.0]])
     up = rng.choice([None, None, "nearest", "bilinear"])
+    if only_tokens:
+        up = "nearest"
     if up is not None:  # a low-resolution map; the oracle gets F.interpolate's materialised version
         lh, lw = int(rng.integers(1, 40)), int(rng.integers(1, 40))
         if up == "nearest" and D % 256 == 0 and rng.random() < 0.7:  # round 6: coarse enough for the token-space path
@@ -139,6 +145,8 @@ for case in range(n_cases):
         cols = torch.randn(n, Dr, generator=g)
         if fused or enc is not None or tok:  # those paths left no weight store behind
             eng.blend_weights(view)
+            if eng.stats()["overflow"] & 2:  # (they never needed the pair capacity either: a store that does not fit here says
+                continue                     # nothing about the render -- next case)
         out = eng.render(view, cols.to(dev)).cpu().numpy()
         rp = orc.project(means.numpy(), quats.numpy(), scales.numpy(), vm.numpy(), K.numpy(), W, H)
         rb = orc.bin_sort(rp, W, H)
