@@ -542,7 +542,8 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
     launch per view, encoder waves and blend waves around an LDS ring of encoded tiles).  None (default) = on images of at least
     SPLIT_ENCODER_MIN_TILES tiles, where a CU's encoder waves have tiles enough to stream; False = never.
     token_space: with upsample="nearest", maps whose texels are at least a 16 x 16 tile wide and high and whose channel count is a
-    multiple of 256 (the dino variant's 64 x 64 x 1024 patch tokens at 1600 x 1060) are back-projected in TOKEN space: the blend
+    multiple of 4, 64 or more (the dino variant's 64 x 64 x 1024 patch tokens at 1600 x 1060; the other DINOv2 backbones' 384,
+    768, 1536) are back-projected in TOKEN space: the blend
     leaves per-(Gaussian, tile) weight sums of the tile's 2 x 2 tokens and every F row that receives weight is updated with ONE
     plain read-modify-write per view from the L2-resident token map -- no atomics, no weight store (csrc/token.hip).  False keeps
     the pixel-slab kernels (gwbp_scatter_upsampled) for such maps too.
@@ -596,7 +597,7 @@ def create_feature_field(means, quats, scales, opacities, viewmats, K, width: in
         for attempt in range(6):  # a capacity overflow invalidates the accumulators: grow the workspace, start over
             if pipeline and len(my_views) > 1:
                 first_map = feature_fn(my_views[0]) if (encoder is not None or upsample == "nearest") else None
-                # the dino shape -- a nearest-upsampled map whose texels are at least a tile wide and high, D % 256 == 0 -- goes
+                # the dino shape -- a nearest-upsampled map whose texels are at least a tile wide and high, D % 4 == 0 -- goes
                 # through token space (Engine.blend_tokens / scatter_tokens); decided on the first map, checked per view
                 token_grid = (tuple(first_map.shape[:2]) if (token_space and upsample == "nearest" and encoder is None
                                                              and Engine.can_scatter_tokens(first_map, height, width)) else None)

@@ -64,15 +64,18 @@ struct TokenApplyArgs {
     int64_t ts_y, ts_x;
     const u32 *sorted_tiles, *sorted_gids; // the intersections in (tile, depth) order: tile id, Gaussian
     int D, W, H;
+    int n_pass; // passes over the channels, 256 NC each
     float scale_f, scale_d;
     float *F, *d;
     Counters *ctr;
 };
 
-// One wave = one Gaussian at a time, ALL its channels: NC chunks of 256 channels side by side (NC x float4 per lane; D = 1024:
-// NC = 4, one pass), so the Gaussian's weight sums are read and decoded once and every token row read / F row read-modify-write
-// of the Gaussian is in flight together.  The operands of the NEXT Gaussian are requested before this one is worked on.
-template <int NC, bool TILE_ORDER>
+// One wave = one Gaussian at a time, all channels of a PASS: NC chunks of 256 channels side by side (NC x float4 per lane; D = 1024:
+// NC = 4, one pass; D = 1536: two passes of NC = 3), so the Gaussian's weight sums are read and decoded once per pass and every
+// token row read / F row read-modify-write of the Gaussian is in flight together.  The operands of the NEXT Gaussian are requested
+// before this one is worked on.  FULL: every (pass, chunk, lane) maps to a channel (D a multiple of 256 NC); otherwise the lanes
+// beyond D are predicated off (any D % 4 == 0: the 384 / 768 / 1536 channels of the other DINOv2 backbones).
+template <int NC, bool TILE_ORDER, bool FULL>
 __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A)
 {
     if (A.ctr->blend_kind != kBlendToken) { // the view in this workspace was not blended by gwbp_blend_tokens
@@ -80,51 +83,40 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
             atomicOr(&A.ctr->overflow, kOverflowMismatch);
         return;
     }
-    // first token column / row of every tile column / row (the index maps at the tiles' first pixels): a few hundred ints that
-    // every entry's token lookup reads -- from LDS, not through a dependent global load in front of the token row reads
     // An intersection-capacity overflow leaves NO emit positions behind (k_emit returns at once, estart[] holds whatever the depth
     // sort left there): the view is invalid anyway (the host grows the workspace and runs it again) and nothing may be read
     // through estart.
     if (A.ctr->overflow & 1u)
         return;
-    if (TILE_ORDER && blockIdx.x * (u32)(64 * kTokWaves) >= A.ctr->n_isect)
+    const u32 n_isect = A.ctr->n_isect;
+    if (TILE_ORDER && blockIdx.x * (u32)(64 * kTokWaves) >= n_isect)
         return; // launched for the capacity (the intersection count lives on the device): blocks beyond the data leave at once
+    // (all returns above are workgroup-uniform; from here on every wave reaches every barrier)
+    // first token column / row of every tile column / row (the index maps at the tiles' first pixels): a few hundred ints that
+    // every entry's token lookup reads -- from LDS, not through a dependent global load in front of the token row reads
     __shared__ int s_tc0[kTokMaxTiles], s_tr0[kTokMaxTiles];
     const int tile_w = (A.W + kTile - 1) / kTile, tile_h = (A.H + kTile - 1) / kTile;
     for (int i = threadIdx.x; i < tile_w; i += 64 * kTokWaves)
         s_tc0[i] = A.xmap[min(i * kTile, A.W - 1)];
     for (int i = threadIdx.x; i < tile_h; i += 64 * kTokWaves)
         s_tr0[i] = A.ymap[min(i * kTile, A.H - 1)];
-    // TILE_ORDER: the 3 x 3 token rows below / right of the first token of the workgroup's first tile, staged in LDS once: the home
-    // Gaussians of that tile (rectangles of up to 2 x 2 tiles reach at most three token columns and rows) read their token rows
-    // from there instead of from L2 -- in tile order the kernel is bound by the L2 -> CU traffic of those rows (12 TB/s)
-    int win_c = 0, win_r = 0;
-    if constexpr (TILE_ORDER) {
-        extern __shared__ __attribute__((aligned(16))) float s_win[];
-        const u32 t0 = A.sorted_tiles[blockIdx.x * (u32)(64 * kTokWaves)];
-        win_c = s_tc0[0], win_r = s_tr0[0]; // (placeholders: the tables are being written; set behind the barrier)
-        __syncthreads();
-        win_c = s_tc0[min((int)(t0 % (u32)tile_w), tile_w - 1)], win_r = s_tr0[min((int)(t0 / (u32)tile_w), tile_h - 1)];
-        const int tc_max = A.xmap[A.W - 1], tr_max = A.ymap[A.H - 1];
-        const int per_row = A.D / 4; // float4 per token row
-        for (int i = threadIdx.x; i < 9 * per_row; i += 64 * kTokWaves) {
-            const int w9 = i / per_row, c4 = i - w9 * per_row;
-            const long long o = (long long)min(win_r + w9 / 3, tr_max) * A.ts_y + (long long)min(win_c + w9 % 3, tc_max) * A.ts_x;
-            reinterpret_cast<f4 *>(s_win)[i] = reinterpret_cast<const f4 *>(A.tokens + o)[c4];
-        }
-    }
     __syncthreads();
     const int lane = (int)(threadIdx.x & 63u), wave = (int)uniform(threadIdx.x >> 6);
+    // TILE_ORDER: the 3 x 3 token rows below / right of the first token of the workgroup's first tile are staged in LDS (per pass:
+    // its 256 NC channels): the home Gaussians of that tile (rectangles of up to 2 x 2 tiles reach at most three token columns
+    // and rows) read their token rows from there instead of from L2
+    int win_c = 0, win_r = 0;
+    if constexpr (TILE_ORDER) {
+        const u32 t0 = A.sorted_tiles[blockIdx.x * (u32)(64 * kTokWaves)];
+        win_c = s_tc0[min((int)(t0 % (u32)tile_w), tile_w - 1)], win_r = s_tr0[min((int)(t0 / (u32)tile_w), tile_h - 1)];
+    }
     // WHICH Gaussians a wave takes.  TILE_ORDER: 64 consecutive entries of the (tile, depth)-sorted intersection list, of which the
     // wave works on the Gaussians whose HOME tile (first tile of the rectangle, emit slot 0) is the entry's tile -- every Gaussian
     // exactly once, consecutive Gaussians read the SAME few token rows (the LDS window).  Otherwise: 16 consecutive Gaussians of
     // the depth order (= the emit order; screen positions at random, token rows gathered from all over the map through L2).
     u32 m_gid = 0, m_cnt = 0, m_es = 0, m_rx = 0, m_ry = 0;
     if constexpr (TILE_ORDER) {
-        const u32 n_isect = A.ctr->n_isect;
         const u32 i0 = (blockIdx.x * (u32)kTokWaves + (u32)wave) * 64u;
-        if (i0 >= n_isect)
-            return;
         if (i0 + (u32)lane < n_isect) {
             const u32 gid = A.sorted_gids[i0 + lane], tile = A.sorted_tiles[i0 + lane];
             const uint2 rc = A.rect[gid];
@@ -135,8 +127,6 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
         }
     } else {
         const int64_t i0 = ((int64_t)blockIdx.x * kTokWaves + wave) * kTokPerWave;
-        if (i0 >= A.N)
-            return;
         if (lane < kTokPerWave && i0 + lane < A.N) {
             m_gid = A.order[i0 + lane];
             m_cnt = A.touched[m_gid];
@@ -147,61 +137,133 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
             }
         }
     }
-    u64 rest = __ballot(m_cnt != 0u);
-    if (rest == 0ull)
-        return;
     const int quad = lane & 3, sl = lane >> 2; // lane = (slot within a batch of 16, token quadrant qx | qy << 1)
-    const int n_pass = A.D / (kTokCh * NC);
-    auto first_batch = [&](int k) -> float { // the first 16 slots' sums of the wave's k-th Gaussian: 256 contiguous bytes
-        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k), es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
-        return (u32)sl < cnt ? A.omega[(size_t)(es + (u32)sl) * 4 + quad] : 0.f;
-    };
-    // the token rows of one Gaussian's weight sums, times the sums, into acc (entry order = emit order: the result does not depend on
-    // which walk reaches the Gaussian); on_first() runs in front of the first token read (wave-uniform).  Returns whether any sum
-    // of the Gaussian is non-zero
-    auto accumulate = [&](int k, float om_first, int pass, f4 (&acc)[NC], float &dsum, auto &&on_first) -> bool {
-        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k), es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
-        const u32 rx = (u32)__builtin_amdgcn_readlane((int)m_rx, k), ry = (u32)__builtin_amdgcn_readlane((int)m_ry, k);
-        const u32 x0 = rx & 0xFFFFu, rw = (rx >> 16) - x0, y0 = ry & 0xFFFFu;
-        const float *tbase = A.tokens + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
-        // one batch of 16 emit slots x 4 quadrants, one sum per lane
-        auto batch = [&](float om, u32 slot, u64 nz) {
-            if (pass == 0)
+    // Which of the wave's Gaussians have weight at all, found lane-parallel: lane j looks through the (up to 16) first sums of ITS
+    // Gaussian, 16 independent loads in flight.  The walk below then only visits Gaussians whose row it will write, which is what
+    // lets it request the NEXT Gaussian's row and sums unconditionally, a Gaussian ahead.
+    u64 mine = __ballot(m_cnt != 0u);
+    if (mine != 0ull) {
+        const u32 last = m_cnt ? min(m_cnt, 16u) - 1u : 0u;
+        const float4 *om4 = reinterpret_cast<const float4 *>(A.omega) + m_es;
+        float4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            v[i] = om4[min((u32)i, last)];
+        u32 bits = 0u; // (OR of the bit patterns without the sign: != 0 exactly when some sum is not +-0; no short circuit, which
+                       // would put a wait and a branch behind every load)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            bits |= (__float_as_uint(v[i].x) | __float_as_uint(v[i].y) | __float_as_uint(v[i].z) | __float_as_uint(v[i].w)) &
+                    0x7FFFFFFFu;
+        mine = __ballot(m_cnt != 0u && (m_cnt > 16u || bits != 0u));
+    }
+    constexpr int kCW = kTokCh * NC; // channels per pass
+    const float *dsrc = A.d ? A.d : A.omega;
+    for (int pass = 0; pass < A.n_pass; ++pass) {
+        const int cbase = pass * kCW; // first channel of the pass
+        if constexpr (TILE_ORDER) {
+            extern __shared__ __attribute__((aligned(16))) float s_win[];
+            if (pass > 0)
+                __syncthreads(); // every wave is done with the previous pass's window
+            const int tc_max = A.xmap[A.W - 1], tr_max = A.ymap[A.H - 1];
+            constexpr int per_row = kCW / 4; // float4 per window row
+            for (int i = threadIdx.x; i < 9 * per_row; i += 64 * kTokWaves) {
+                const int w9 = i / per_row, c4 = i - w9 * per_row;
+                if (FULL || cbase + c4 * 4 < A.D) {
+                    const long long o = (long long)min(win_r + w9 / 3, tr_max) * A.ts_y + (long long)min(win_c + w9 % 3, tc_max) * A.ts_x;
+                    reinterpret_cast<f4 *>(s_win)[i] = *reinterpret_cast<const f4 *>(A.tokens + o + cbase + c4 * 4);
+                }
+            }
+            __syncthreads();
+        }
+        u64 rest = mine;
+        if (rest == 0ull)
+            continue; // (wave-uniform; the wave still meets the others at the barriers)
+        bool valid[NC]; // does this lane's float4 of chunk c hold channels?  (the last chunks of a D that is no multiple of 256 NC)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            valid[c] = FULL || cbase + c * kTokCh + lane * 4 < A.D;
+        // the token rows of one Gaussian's weight sums, times the sums, into acc.  Returns whether any sum is non-zero
+        auto accumulate = [&](int k, float om_first, f4 (&acc)[NC], float &dsum) -> bool {
+            const u32 cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k), es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
+            const u32 rx = (u32)__builtin_amdgcn_readlane((int)m_rx, k), ry = (u32)__builtin_amdgcn_readlane((int)m_ry, k);
+            const u32 x0 = rx & 0xFFFFu, rw = (rx >> 16) - x0, y0 = ry & 0xFFFFu;
+            const float *tbase = A.tokens + (size_t)cbase + (size_t)lane * 4;
+            // one batch of 16 emit slots x 4 quadrants, one sum per lane
+            auto batch = [&](float om, u32 slot, u64 nz) {
                 dsum += om;
-            // the token under this lane's (tile, quadrant): first token of the tile + (qx, qy); only dereferenced where om != 0,
-            // i.e. where the blend found a pixel of that token
-            const u32 ty = y0 + slot / rw, tx = x0 + slot % rw;
-            const int tc = s_tc0[min(tx, (u32)tile_w - 1u)] + (quad & 1);
-            const int tr = s_tr0[min(ty, (u32)tile_h - 1u)] + (quad >> 1);
-            u64 miss = nz;
-            if constexpr (TILE_ORDER) {
-                // the entries whose token lies in the workgroup's LDS window first, in a loop of their own without a global load
-                // (one loop with both sources has to wait for EVERYTHING in flight at the join, the next Gaussian's row included)
-                extern __shared__ __attribute__((aligned(16))) float s_win[];
-                const int er = tr - win_r, ec = tc - win_c;
-                const bool inside = (u32)er < 3u && (u32)ec < 3u;
-                u64 hits = nz & __ballot(inside);
-                miss = nz & ~hits;
-                const int woff = (er * 3 + ec) * A.D + pass * (kTokCh * NC); // (floats; only read from lanes inside)
-                while (hits != 0ull) { // two entries' rows in flight
+                // the token under this lane's (tile, quadrant): first token of the tile + (qx, qy); only dereferenced where
+                // om != 0, i.e. where the blend found a pixel of that token
+                const u32 ty = y0 + slot / rw, tx = x0 + slot % rw;
+                const int tc = s_tc0[min(tx, (u32)tile_w - 1u)] + (quad & 1);
+                const int tr = s_tr0[min(ty, (u32)tile_h - 1u)] + (quad >> 1);
+                u64 miss = nz;
+                if constexpr (TILE_ORDER) {
+                    // the entries whose token lies in the workgroup's LDS window first, in a loop of their own without a global
+                    // load (one loop with both sources has to wait for EVERYTHING in flight at the join, the next Gaussian's row
+                    // included)
+                    extern __shared__ __attribute__((aligned(16))) float s_win[];
+                    const int er = tr - win_r, ec = tc - win_c;
+                    const bool inside = (u32)er < 3u && (u32)ec < 3u;
+                    u64 hits = nz & __ballot(inside);
+                    miss = nz & ~hits;
+                    const int woff = (er * 3 + ec) * kCW; // (floats; only read from lanes inside)
+                    while (hits != 0ull) {                // two entries' rows in flight
+                        f4 t[2][NC];
+                        float w[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            w[u] = 0.f;
+                            if (hits != 0ull) { // wave-uniform
+                                const int l = __ffsll((long long)hits) - 1;
+                                hits &= hits - 1;
+                                w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(om), l));
+                                const float *wrow = s_win + __builtin_amdgcn_readlane(woff, l) + lane * 4;
+#pragma unroll
+                                for (int c = 0; c < NC; ++c) // (lanes beyond D read LDS nobody wrote: never stored)
+                                    t[u][c] = *reinterpret_cast<const f4 *>(wrow + c * kTokCh);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            if (w[u] != 0.f) { // (wave-uniform; a skipped slot must not turn 0 x NaN into NaN)
+#pragma unroll
+                                for (int c = 0; c < NC; ++c) {
+                                    acc[c].x = __builtin_fmaf(w[u], t[u][c].x, acc[c].x);
+                                    acc[c].y = __builtin_fmaf(w[u], t[u][c].y, acc[c].y);
+                                    acc[c].z = __builtin_fmaf(w[u], t[u][c].z, acc[c].z);
+                                    acc[c].w = __builtin_fmaf(w[u], t[u][c].w, acc[c].w);
+                                }
+                            }
+                    }
+                }
+                if (miss == 0ull)
+                    return;
+                const long long toff = (long long)tr * A.ts_y + (long long)tc * A.ts_x;
+                const int tlo = (int)(u32)toff, thi = (int)(toff >> 32);
+                while (miss != 0ull) { // two entries' rows (2 x NC loads) in flight
                     f4 t[2][NC];
                     float w[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         w[u] = 0.f;
-                        if (hits != 0ull) { // wave-uniform
-                            const int l = __ffsll((long long)hits) - 1;
-                            hits &= hits - 1;
+                        if (miss != 0ull) { // wave-uniform
+                            const int l = __ffsll((long long)miss) - 1;
+                            miss &= miss - 1;
                             w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(om), l));
-                            const float *wrow = s_win + __builtin_amdgcn_readlane(woff, l) + lane * 4;
+                            const long long o = ((long long)__builtin_amdgcn_readlane(thi, l) << 32) |
+                                                (long long)(u32)__builtin_amdgcn_readlane(tlo, l);
 #pragma unroll
-                            for (int c = 0; c < NC; ++c)
-                                t[u][c] = *reinterpret_cast<const f4 *>(wrow + c * kTokCh);
+                            for (int c = 0; c < NC; ++c) {
+                                t[u][c] = f4{0.f, 0.f, 0.f, 0.f};
+                                if (valid[c])
+                                    t[u][c] = *reinterpret_cast<const f4 *>(tbase + o + c * kTokCh);
+                            }
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
-                        if (w[u] != 0.f) { // (wave-uniform; a skipped slot must not turn 0 x NaN into NaN)
+                        if (w[u] != 0.f) {
 #pragma unroll
                             for (int c = 0; c < NC; ++c) {
                                 acc[c].x = __builtin_fmaf(w[u], t[u][c].x, acc[c].x);
@@ -211,106 +273,46 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                             }
                         }
                 }
-            }
-            if (miss == 0ull)
-                return;
-            const long long toff = (long long)tr * A.ts_y + (long long)tc * A.ts_x;
-            const int tlo = (int)(u32)toff, thi = (int)(toff >> 32);
-            while (miss != 0ull) { // two entries' rows (2 x NC loads) in flight
-                f4 t[2][NC];
-                float w[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    w[u] = 0.f;
-                    if (miss != 0ull) { // wave-uniform
-                        const int l = __ffsll((long long)miss) - 1;
-                        miss &= miss - 1;
-                        w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(om), l));
-                        const long long o = ((long long)__builtin_amdgcn_readlane(thi, l) << 32) |
-                                            (long long)(u32)__builtin_amdgcn_readlane(tlo, l);
-#pragma unroll
-                        for (int c = 0; c < NC; ++c)
-                            t[u][c] = *reinterpret_cast<const f4 *>(tbase + o + c * kTokCh);
-                    }
+            };
+            // the first batch's sums are in registers already; the loop over further batches (rectangles of more than 16 tiles)
+            // is a loop of its own, so that the common case has no load of sums in front of its token reads
+            bool any = false;
+            {
+                const u64 nz = __ballot(om_first != 0.f);
+                if (nz != 0ull) {
+                    any = true;
+                    batch(om_first, (u32)sl, nz);
                 }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (w[u] != 0.f) {
-#pragma unroll
-                        for (int c = 0; c < NC; ++c) {
-                            acc[c].x = __builtin_fmaf(w[u], t[u][c].x, acc[c].x);
-                            acc[c].y = __builtin_fmaf(w[u], t[u][c].y, acc[c].y);
-                            acc[c].z = __builtin_fmaf(w[u], t[u][c].z, acc[c].z);
-                            acc[c].w = __builtin_fmaf(w[u], t[u][c].w, acc[c].w);
-                        }
-                    }
             }
+            for (u32 s0 = 16u; s0 < cnt; s0 += 16u) {
+                const u32 slot = s0 + (u32)sl;
+                const float om = slot < cnt ? A.omega[(size_t)(es + slot) * 4 + quad] : 0.f;
+                const u64 nz = __ballot(om != 0.f);
+                if (nz == 0ull)
+                    continue;
+                any = true;
+                batch(om, slot, nz);
+            }
+            return any;
         };
-        // the first batch's sums are in registers already; the loop over further batches (rectangles of more than 16 tiles) is
-        // a loop of its own, so that the common case has no load of sums in front of its token reads
-        bool any = false;
-        {
-            const u64 nz = __ballot(om_first != 0.f);
-            if (nz != 0ull) {
-                any = true;
-                on_first();
-                batch(om_first, (u32)sl, nz);
-            }
-        }
-        for (u32 s0 = 16u; s0 < cnt; s0 += 16u) {
-            const u32 slot = s0 + (u32)sl;
-            const float om = slot < cnt ? A.omega[(size_t)(es + slot) * 4 + quad] : 0.f;
-            const u64 nz = __ballot(om != 0.f);
-            if (nz == 0ull)
-                continue;
-            if (!any) {
-                any = true;
-                on_first();
-            }
-            batch(om, slot, nz);
-        }
-        return any;
-    };
-    auto pop = [&]() -> int { // the wave's next Gaussian (a lane index), -1 behind the last
-        if (rest == 0ull)
-            return -1;
-        const int k = __ffsll((long long)rest) - 1;
-        rest &= rest - 1;
-        return k;
-    };
-#ifndef GWBP_TOKEN_NO_PREFETCH
-    if (n_pass == 1) { // (wave-uniform) all channels in one pass, D = 256 NC
-        // Which of the wave's Gaussians have weight at all, found lane-parallel: lane j looks through the (up to 16) first sums of
-        // ITS Gaussian, 16 independent loads in flight.  The walk below then only visits Gaussians whose row it will write, which is
-        // what lets it request the NEXT Gaussian's row and sums unconditionally, a Gaussian ahead.
-        {
-            const u32 last = m_cnt ? min(m_cnt, 16u) - 1u : 0u;
-            const float4 *om4 = reinterpret_cast<const float4 *>(A.omega) + m_es;
-            float4 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                v[i] = om4[min((u32)i, last)];
-            u32 bits = 0u; // (OR of the bit patterns without the sign: != 0 exactly when some sum is not +-0; no short circuit,
-                           // which would put a wait and a branch behind every load)
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                bits |= (__float_as_uint(v[i].x) | __float_as_uint(v[i].y) | __float_as_uint(v[i].z) | __float_as_uint(v[i].w)) &
-                        0x7FFFFFFFu;
-            rest = __ballot(m_cnt != 0u && (m_cnt > 16u || bits != 0u));
+        auto pop = [&]() -> int { // the wave's next Gaussian (a lane index), -1 behind the last
             if (rest == 0ull)
-                return;
-        }
+                return -1;
+            const int k = __ffsll((long long)rest) - 1;
+            rest &= rest - 1;
+            return k;
+        };
         // (sums, row, d) of a Gaussian: requests without conditions -- the waits in the walk are counted ones (vmcnt retires in
-        // order; a wait in front of a path-dependent number of younger loads would have to drain them all)
-        const float *dsrc = A.d ? A.d : A.omega;
+        // order and counts stores; a wait in front of a path-dependent number of younger loads would have to drain them all)
         auto request = [&](int k, float &om, f4 (&fold)[NC], float &dv) {
             const u32 cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k), es = (u32)__builtin_amdgcn_readlane((int)m_es, k);
             const u32 gid = (u32)__builtin_amdgcn_readlane((int)m_gid, k);
             om = A.omega[(size_t)(es + min((u32)sl, cnt - 1u)) * 4 + quad];
-            const float *row = A.F + (size_t)gid * (size_t)A.D + (size_t)lane * 4;
+            const float *row = A.F + (size_t)gid * (size_t)A.D + (size_t)cbase + (size_t)lane * 4;
 #pragma unroll
             for (int c = 0; c < NC; ++c)
-                fold[c] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(row + c * kTokCh));
+                if (valid[c])
+                    fold[c] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(row + c * kTokCh));
             dv = dsrc[A.d ? gid : 0u];
         };
         // one Gaussian: request the next one's operands into the OTHER register set, work on this one, store; returns the next
@@ -323,9 +325,9 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
             for (int c = 0; c < NC; ++c)
                 acc[c] = f4{0.f, 0.f, 0.f, 0.f};
             float dsum = 0.f;
-            const bool any = accumulate(kc, (u32)sl < cnt ? om_c : 0.f, 0, acc, dsum, [] {});
+            const bool any = accumulate(kc, (u32)sl < cnt ? om_c : 0.f, acc, dsum);
             if (any) { // (a Gaussian of more than 16 slots may still be without weight: nothing is written then)
-                float *frow = A.F + (size_t)gid * (size_t)A.D + (size_t)lane * 4;
+                float *frow = A.F + (size_t)gid * (size_t)A.D + (size_t)cbase + (size_t)lane * 4;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     f4 r = fold_c[c];
@@ -333,9 +335,10 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                     r.y = __builtin_fmaf(A.scale_f, acc[c].y, r.y);
                     r.z = __builtin_fmaf(A.scale_f, acc[c].z, r.z);
                     r.w = __builtin_fmaf(A.scale_f, acc[c].w, r.w);
-                    __builtin_nontemporal_store(r, reinterpret_cast<f4 *>(frow + c * kTokCh));
+                    if (valid[c])
+                        __builtin_nontemporal_store(r, reinterpret_cast<f4 *>(frow + c * kTokCh));
                 }
-                if (A.d) { // the wave owns d[gid] as well: plain read-modify-write
+                if (pass == 0 && A.d) { // the wave owns d[gid] as well: plain read-modify-write
                     const float tot = wave_sum(dsum);
                     if (lane == 0)
                         A.d[gid] = __builtin_fmaf(A.scale_d, tot, d_c);
@@ -355,49 +358,6 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
             if (kc < 0)
                 break;
         }
-        return;
-    }
-#endif
-    // several passes over the channels (D = 768, 1280 ...): the sums of the next Gaussian are requested a Gaussian ahead, the row
-    // when the first weight is seen
-    float om_next = first_batch(__ffsll((long long)rest) - 1);
-    while (rest != 0ull) {
-        const int k = pop();
-        const float om_first = om_next;
-        if (rest != 0ull)
-            om_next = first_batch(__ffsll((long long)rest) - 1); // lands under this Gaussian's row traffic
-        const u32 gid = (u32)__builtin_amdgcn_readlane((int)m_gid, k), cnt = (u32)__builtin_amdgcn_readlane((int)m_cnt, k);
-        if (cnt <= 16u && __ballot(om_first != 0.f) == 0ull)
-            continue; // visible, binned, but no pixel with weight: F and d keep their values (nothing is read or written)
-        float dsum = 0.f;
-        for (int pass = 0; pass < n_pass; ++pass) {
-            float *frow = A.F + (size_t)gid * (size_t)A.D + (size_t)pass * (kTokCh * NC) + (size_t)lane * 4;
-            f4 acc[NC], fold[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                acc[c] = f4{0.f, 0.f, 0.f, 0.f};
-            const bool any = accumulate(k, om_first, pass, acc, dsum, [&] {
-            // first weight of this Gaussian: start the row's read now, it lands under the token reads
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    fold[c] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(frow + c * kTokCh));
-            });
-            if (!any)
-                break;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                fold[c].x = __builtin_fmaf(A.scale_f, acc[c].x, fold[c].x);
-                fold[c].y = __builtin_fmaf(A.scale_f, acc[c].y, fold[c].y);
-                fold[c].z = __builtin_fmaf(A.scale_f, acc[c].z, fold[c].z);
-                fold[c].w = __builtin_fmaf(A.scale_f, acc[c].w, fold[c].w);
-                __builtin_nontemporal_store(fold[c], reinterpret_cast<f4 *>(frow + c * kTokCh));
-            }
-            if (pass == 0 && A.d) { // the wave owns d[gid] as well: plain read-modify-write
-                const float tot = wave_sum(dsum);
-                if (lane == 0)
-                    A.d[gid] = __builtin_fmaf(A.scale_d, tot, A.d[gid]);
-            }
-        }
     }
 }
 
@@ -411,9 +371,8 @@ int launch_zero_omega(const Layout &L, const Ws &W, hipStream_t s)
 int launch_token_apply(const Layout &L, const Ws &W, const ViewDev &V, const float *tokens, int64_t ts_y, int64_t ts_x, int D,
                        const int32_t *ymap, const int32_t *xmap, float scale_f, float scale_d, float *F, float *d, hipStream_t s)
 {
-    if (D < kTokCh || D % kTokCh != 0)
-        return set_error(GWBP_EUNSUPPORTED, "gwbp_scatter_tokens: D must be a multiple of %d (got %d); use gwbp_scatter_upsampled", kTokCh,
-                         D);
+    if (D < 4 || D % 4 != 0)
+        return set_error(GWBP_EUNSUPPORTED, "gwbp_scatter_tokens: D must be a multiple of 4 (got %d); use gwbp_scatter_upsampled", D);
     if (!tokens || !ymap || !xmap || (L.n > 0 && !F))
         return set_error(GWBP_EINVAL, "gwbp_scatter_tokens: null tokens / index maps / F");
     if (ts_y < 0 || ts_x < D || (ts_y & 3) || (ts_x & 3) || (reinterpret_cast<uintptr_t>(tokens) & 15) ||
@@ -431,31 +390,37 @@ int launch_token_apply(const Layout &L, const Ws &W, const ViewDev &V, const flo
     A.ymap = ymap, A.xmap = xmap, A.tokens = tokens, A.ts_y = ts_y, A.ts_x = ts_x;
     A.D = D, A.W = V.W, A.H = V.H, A.scale_f = scale_f, A.scale_d = scale_d, A.F = F, A.d = d;
     A.ctr = W.counters;
-    // 256-channel chunks a wave handles side by side: as many as divide D (4, 2, 1)
-    const int nc = D % (4 * kTokCh) == 0 ? 4 : D % (2 * kTokCh) == 0 ? 2 : 1;
+    // 256-channel chunks: as few passes as four chunks side by side allow, the chunks spread evenly over them (D = 1024: one pass
+    // of 4; 1536: two passes of 3; 384: one pass of 2 whose second chunk is half empty)
+    const int n_chunk = (D + kTokCh - 1) / kTokCh;
+    A.n_pass = (n_chunk + 3) / 4;
+    const int nc = (n_chunk + A.n_pass - 1) / A.n_pass;
+    const bool full = D % kTokCh == 0 && n_chunk == A.n_pass * nc;
     const int fin = sort_passes(V.tile_w * V.tile_h) & 1; // where the tile sort left its result
     A.sorted_tiles = W.keys[fin], A.sorted_gids = W.vals[fin];
-    // the tile-order walk with the workgroup's 3 x 3 token window in LDS (9 D floats: D <= 1024 within the default 48 KB... 1280);
-    // wider maps, and -DGWBP_TOKEN_DEPTH_ORDER builds (same-box A/B), walk the Gaussians in depth order and read every row from L2
-    const size_t lds = (size_t)9 * D * sizeof(float);
+    // the tile-order walk with the workgroup's 3 x 3 token window in LDS (9 x 256 NC floats per pass: at most 36 KB, four workgroups
+    // per CU); -DGWBP_TOKEN_DEPTH_ORDER builds (same-box A/B) walk the Gaussians in depth order and read every token row from L2
 #ifndef GWBP_TOKEN_DEPTH_ORDER
-    const bool tile_order = lds <= 48 * 1024;
+    constexpr bool tile_order = true;
 #else
-    const bool tile_order = false;
+    constexpr bool tile_order = false;
 #endif
+    const size_t lds = tile_order ? (size_t)9 * nc * kTokCh * sizeof(float) : 0;
     const int64_t blocks = tile_order ? (L.isect_cap + 64 * kTokWaves - 1) / (64 * kTokWaves) : (L.n + kTokGroup - 1) / kTokGroup;
     if (blocks > 0x7FFFFFFFll)
         return set_error(GWBP_EINVAL, "gwbp_scatter_tokens: grid too large");
     const dim3 grid((unsigned)blocks), block(64 * kTokWaves);
 #define GWBP_TOK_LAUNCH(NCV)                                                                                                   \
     do {                                                                                                                       \
-        if (tile_order)                                                                                                        \
-            hipLaunchKernelGGL((k_token_apply<NCV, true>), grid, block, lds, s, A);                                            \
+        if (full)                                                                                                              \
+            hipLaunchKernelGGL((k_token_apply<NCV, tile_order, true>), grid, block, lds, s, A);                                \
         else                                                                                                                   \
-            hipLaunchKernelGGL((k_token_apply<NCV, false>), grid, block, 0, s, A);                                             \
+            hipLaunchKernelGGL((k_token_apply<NCV, tile_order, false>), grid, block, lds, s, A);                               \
     } while (0)
     if (nc == 4)
         GWBP_TOK_LAUNCH(4);
+    else if (nc == 3)
+        GWBP_TOK_LAUNCH(3);
     else if (nc == 2)
         GWBP_TOK_LAUNCH(2);
     else

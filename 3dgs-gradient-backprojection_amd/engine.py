@@ -285,7 +285,7 @@ class Engine:
         return sy, sx, sc, feats.shape[2]
 
     # ---- token space: the dino variant's nearest-upsampled patch-token map (backproject.py:242-249) ------------------
-    TOKEN_CHUNK = 256  # gwbp_scatter_tokens walks the channels in chunks of 256 (one float4 per lane)
+    TOKEN_MIN_DIM = 64  # gwbp_scatter_tokens: one float4 per lane and 256-channel chunk; narrower maps leave 3/4 of a wave idle
     TOKEN_MAX_VIEW = 4096  # ... and keeps per-tile-column / -row tables of 256 entries in LDS (token.hip kTokMaxTiles)
 
     _TOKEN_GEOMETRY: Dict[Tuple[int, int, int, int], bool] = {}
@@ -309,7 +309,8 @@ class Engine:
 
     @classmethod
     def can_scatter_tokens(cls, tokens: torch.Tensor, height: int, width: int) -> bool:
-        """Low-resolution maps the token-space path takes: [h, w, D] float32 on the device, D % 256 == 0, channel-contiguous
+        """Low-resolution maps the token-space path takes: [h, w, D] float32 on the device, D % 4 == 0 and D >= 64 (the 384 / 768 /
+        1024 / 1536 channels of the DINOv2 backbones), channel-contiguous
         16-B aligned rows, texels at least a tile wide and high (token_geometry_ok), views of at most 4096 x 4096 pixels.
         Anything else goes through blend_weights + scatter(upsample="nearest")."""
         if tokens.dim() != 3 or not tokens.is_cuda or tokens.dtype != torch.float32:
@@ -318,7 +319,7 @@ class Engine:
             return False
         sy, sx, sc = tokens.stride()
         D = tokens.shape[2]
-        return (D >= cls.TOKEN_CHUNK and D % cls.TOKEN_CHUNK == 0 and sc == 1 and sy % 4 == 0 and sx % 4 == 0 and sy >= 0
+        return (D >= cls.TOKEN_MIN_DIM and D % 4 == 0 and sc == 1 and sy % 4 == 0 and sx % 4 == 0 and sy >= 0
                 and sx >= D and tokens.data_ptr() % 16 == 0
                 and cls.token_geometry_ok(tokens.shape[0], tokens.shape[1], int(height), int(width)))
 
@@ -343,7 +344,7 @@ class Engine:
         if getattr(self, "_tokens", None) != (int(tokens.shape[0]), int(tokens.shape[1])):
             raise GwbpError("scatter_tokens needs blend_tokens(view, h, w) of the same view and map size first")
         if not self.can_scatter_tokens(tokens, view.height, view.width):
-            raise GwbpError(f"scatter_tokens: [h,w,D] float32 map with D % 256 == 0, channel-contiguous 16-B aligned rows and texels "
+            raise GwbpError(f"scatter_tokens: [h,w,D] float32 map with D % 4 == 0, D >= 64, channel-contiguous 16-B aligned rows and texels "
                             f"of at least a tile at a view of at most {self.TOKEN_MAX_VIEW} x {self.TOKEN_MAX_VIEW} pixels required, got "
                             f"{tuple(tokens.shape)} strides {tuple(tokens.stride())} at {view.width} x {view.height}")
         D = tokens.shape[2]

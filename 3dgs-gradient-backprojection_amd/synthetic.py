@@ -47,6 +47,13 @@ CONFIGS: Dict[str, Config] = {
     # dino: 64 x 64 x 1024 patch tokens, nearest-upsampled, .mean() reductions (backproject.py:201,242-249,263,283)
     "DINO64": Config("DINO64", 1_000_000, 200, 1600, 1060, 1024, 0.004, True, lowres=(64, 64), upsample="nearest",
                      reduction="mean", normalize=False),
+    # ... and the same loop with the other DINOv2 backbones' widths (vits14 384, vitb14 768, vitg14 1536; 64 x 64 tokens each)
+    "DINO64S": Config("DINO64S", 1_000_000, 200, 1600, 1060, 384, 0.004, True, lowres=(64, 64), upsample="nearest",
+                      reduction="mean", normalize=False),
+    "DINO64B": Config("DINO64B", 1_000_000, 200, 1600, 1060, 768, 0.004, True, lowres=(64, 64), upsample="nearest",
+                      reduction="mean", normalize=False),
+    "DINO64G": Config("DINO64G", 1_000_000, 200, 1600, 1060, 1536, 0.004, True, lowres=(64, 64), upsample="nearest",
+                      reduction="mean", normalize=False),
     # lseg: 480 x 480 x 512 normalised map, bilinearly upsampled, .sum() reductions (backproject.py:102-113,127,145)
     "LSEG480": Config("LSEG480", 1_000_000, 200, 1600, 1060, 512, 0.004, True, lowres=(480, 480), upsample="bilinear"),
     # small shapes used by the parity tests and smoke()

@@ -7,7 +7,7 @@ step    : one view of the hot path: project -> bin/sort -> blend weights -> scat
           (backproject.py:115-151), inputs resident in HBM.  Views shard over ranks (r, r+R, ...); after the last
           step the ranks' partial F/d are summed with ONE all-reduce (RCCL over xGMI) inside the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C1|C4|C5|DINO64|LSEG480] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C1|C4|C5|DINO64|DINO64S|DINO64B|DINO64G|LSEG480] [--no-cpu-baseline]
       (DINO64 / LSEG480: the C2 scene with the reference's feature maps AS IT PRODUCES THEM -- 64x64x1024 dino patch tokens,
        nearest-upsampled, .mean() reductions; the 480x480x512 lseg map, bilinearly upsampled -- backproject.py:242-249, :102-113)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \

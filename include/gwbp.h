@@ -183,7 +183,8 @@ GWBP_API int gwbp_blend_scatter_encoded(const gwbp_caps *caps, void *workspace, 
  * result is invalid -- use gwbp_scatter_upsampled for finer maps.  The weights are gwbp_blend_weights' bit for bit (the alpha map
  * too); F and d equal gwbp_scatter_upsampled's up to summation order.  After gwbp_blend_tokens the workspace holds NO weight
  * store (gwbp_stats.reserved reads 3): gwbp_scatter / gwbp_render of that view add nothing.
- * gwbp_scatter_tokens: tokens[row * ts_y + col * ts_x + c], channel-contiguous 16-B aligned rows, D % 256 == 0; d may be NULL;
+ * gwbp_scatter_tokens: tokens[row * ts_y + col * ts_x + c], channel-contiguous 16-B aligned rows, D % 4 == 0 (256-channel chunks,
+ * the last one masked; GWBP_EUNSUPPORTED otherwise), views of at most 4096 x 4096 pixels; d may be NULL;
  * needs gwbp_project + gwbp_bin_sort + gwbp_blend_tokens of the same view in this workspace (anything else sets overflow bit 2
  * and leaves F and d untouched). */
 GWBP_API int gwbp_blend_tokens(const gwbp_caps *caps, void *workspace, size_t workspace_bytes, const gwbp_view *view_host,

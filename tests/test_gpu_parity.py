@@ -717,12 +717,13 @@ def test_scatter_nearest_upsampled_lowres_map(orc, dev, D):
         eng.scatter(view, low.to(dev), F1, d1)  # a low-resolution map without upsample= is a shape error
 
 
-@pytest.mark.parametrize("D", [256, 512, 768, 1024])
+@pytest.mark.parametrize("D", [64, 132, 256, 384, 512, 768, 1024, 1280, 1536, 2052])
 def test_token_space_scatter_against_oracle(orc, dev, D):
     """Round 6: the dino variant in TOKEN space (backproject.py:242-289).  An 8 x 12 map at 200 x 136 has texels of 17 x 16.7
     pixels -- at least a tile -- so every tile sees at most 2 x 2 of them: Engine.blend_tokens leaves per-record token-quadrant
-    weight sums, Engine.scatter_tokens applies them with one plain read-modify-write per F row (1, 2, 3 and 4 channel chunks:
-    768 takes the chunk map that is not XCD-aligned).  Against the oracle fed the materialised F.interpolate(mode="nearest") map,
+    weight sums, Engine.scatter_tokens applies them with one plain read-modify-write per F row -- any D % 4 == 0 from 64 up: one
+    to four 256-channel chunks side by side in one pass (64 / 132: most of the wave masked off; 384: a half chunk), two passes
+    (1280: a chunk that does not exist, 1536), three passes with a 4-channel tail (2052).  Against the oracle fed the materialised F.interpolate(mode="nearest") map,
     against the pixel-slab path, alpha map bit for bit with blend_weights, and -- no atomics -- bit-identical on a rerun."""
     cfg, sc = scene_np("T1")
     d, h = to_dev(sc, dev), npy(sc)

@@ -16,7 +16,7 @@ from util import rel_row_err  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-only_tokens = len(sys.argv) > 3 and sys.argv[3] == "tokens"  # every case a nearest-upsampled coarse map with D % 256 == 0
+only_tokens = len(sys.argv) > 3 and sys.argv[3] == "tokens"  # every case a nearest-upsampled coarse map with D % 4 == 0
 dev = torch.device("cuda:0")
 orc.build()
 DIMS = [1, 3, 4, 7, 8, 12, 16, 17, 32, 40, 64, 65, 100, 128, 130, 256, 384, 512, 768, 1024]
@@ -34,7 +34,7 @@ for case in range(n_cases):
     W, H = int(rng.integers(1, 260)), int(rng.integers(1, 200))
     D = int(rng.choice(DIMS))
     if only_tokens:
-        D = int(rng.choice([256, 256, 512, 768, 1024, 1280, 1536]))
+        D = int(rng.choice([256, 512, 768, 1024, 1280, 1536, 384, 64, 4 * int(rng.integers(16, 520))]))
         W, H = int(rng.integers(16, 400)), int(rng.integers(16, 300))
     s0 = float(10 ** rng.uniform(-2.6, -0.3))
     g = torch.Generator().manual_seed(seed0 + case)
@@ -57,7 +57,7 @@ for case in range(n_cases):
         up = "nearest"
     if up is not None:  # a low-resolution map; the oracle gets F.interpolate's materialised version
         lh, lw = int(rng.integers(1, 40)), int(rng.integers(1, 40))
-        if up == "nearest" and D % 256 == 0 and rng.random() < 0.7:  # round 6: coarse enough for the token-space path
+        if up == "nearest" and D % 4 == 0 and D >= 64 and rng.random() < 0.7:  # round 6: coarse enough for the token-space path
             lh, lw = int(rng.integers(1, max(2, H // 16 + 1))), int(rng.integers(1, max(2, W // 16 + 1)))
         low = torch.randn(lh, lw, D, generator=g)
         if D < 4:
