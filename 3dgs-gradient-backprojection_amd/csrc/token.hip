@@ -13,12 +13,12 @@
 // no atomics, no weight store, no slabs, no carry rows, no sort by Gaussian.
 //
 // HBM traffic per view: 8 B x D per Gaussian that receives weight (C2 geometry, D = 1024: 0.53 M rows -> 4.4 GB) + the 16-B sums
-// (0.06 GB); the token rows (about five 4-KB rows per touched Gaussian) come from L2 / Infinity Cache.
+// (0.06 GB); the token rows (about five 4-KB rows per touched Gaussian) come from LDS, the few outside the window from L2.
 //
-// Work map (k_token_apply<NC, true>, the product for D <= 1280): a workgroup of four waves takes 256 consecutive entries of the
+// Work map (k_token_apply<NC, true, FULL>, the product): a workgroup of four waves takes 256 consecutive entries of the
 // (tile, depth)-sorted intersection list and works on the Gaussians whose HOME tile -- first tile of their rectangle, emit slot 0 --
 // is the entry's tile: every Gaussian exactly once, neighbours on the screen back to back.  The 3 x 3 token rows under the first
-// entry's tile are staged in LDS once (9 D floats); a Gaussian's rectangle of up to 2 x 2 tiles reaches at most three token columns
+// entry's tile are staged in LDS (per pass over the channels: 9 x 256 NC floats); a Gaussian's rectangle of up to 2 x 2 tiles reaches at most three token columns
 // and rows, so almost every token read is an LDS read.  A wave first finds, lane-parallel, which of its Gaussians carry weight at
 // all, then walks those with two register sets: the NEXT Gaussian's F row, first 16 sums and d are requested (unconditionally, so
 // that the waits are counted ones) before the current one is multiplied out and stored -- a row's read, its write and the next
@@ -27,9 +27,9 @@
 // Measured per C2-geometry view at D = 1024, alone / in the pipeline, same box each step (profiles/r6_token_*.txt, DESIGN.md
 // section 9): first version -- one (Gaussian, 256-channel chunk) per wave iteration, chunk tied to the XCD -- 2.17 ms; one wave
 // per Gaussian over all channels in depth order 1.27 / 1.85; tile order + LDS window 1.07 / 1.73; + the request one Gaussian
-// ahead 0.87 / 1.42 (4.45 GB of 4-KB rows read and written at 5.1 TB/s).  Depth order (k_token_apply<NC, false>) stays for
-// maps too wide for the window and as the -DGWBP_TOKEN_DEPTH_ORDER A/B build; -DGWBP_TOKEN_NO_PREFETCH builds the walk without
-// the second register set.  Tried and dropped: XCD-local channel groups (1.32-1.66 alone), tile order without the window (no gain:
+// ahead 0.87 / 1.42 (4.45 GB of 4-KB rows read and written at 5.1 TB/s).  Depth order (k_token_apply<NC, false, FULL>) stays as
+// the -DGWBP_TOKEN_DEPTH_ORDER A/B build.  Channels: 256-channel chunks, up to four side by side per pass, as few passes as that
+// allows (D = 1024: 1 x 4; 1536: 2 x 3; 384: 1 x 2 with half a chunk masked off) -- any D % 4 == 0.  Tried and dropped: XCD-local channel groups (1.32-1.66 alone), tile order without the window (no gain:
 // the L2 gathers did not bind, the per-Gaussian latency chain did), a 2 x 2 register window, channel-group waves.
 #include "gwbp_dev.h"
 

@@ -752,6 +752,9 @@ def test_token_space_scatter_against_oracle(orc, dev, D):
     assert st1["blend_kind"] == 3
     assert torch.equal(a_tok, a_ref)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])  # deterministic: no atomics
+    F2 = torch.full((cfg.n_gaussians, D), 0.25, device=dev)
+    eng.scatter_tokens(view, low.to(dev), F2, None, 2.0, 3.0)  # d is optional (the sums stay in the workspace until the next blend)
+    assert torch.equal(F2, res[0][0])
     Fr = np.zeros((cfg.n_gaussians, D), np.float64)
     dr = np.zeros(cfg.n_gaussians, np.float64)
     orc.backproject_view(h["means"], h["quats"], h["scales"], h["opac"], h["vms"][0], h["K"], cfg.width, cfg.height, up, Fr, dr)
