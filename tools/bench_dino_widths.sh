@@ -1,3 +1,6 @@
+#!/bin/bash
+# On the GPU box: the dino loop at the other DINOv2 widths (DINO64S / B / G = 384 / 768 / 1536 channels, 64 x 64 tokens, C2 geometry): token space
+# with CPU baseline + oracle_check, the pixel-slab kernels (--token-space off), and --serial (k_token_apply alone).  -> profiles/r6_dino_widths.txt
 mkdir -p gpurun_out/dinow
 for C in DINO64S DINO64B DINO64G; do
   timeout 400 python bench.py --config $C --steps 100 > gpurun_out/dinow/bench_${C}_default.json 2> gpurun_out/dinow/err_$C.txt || tail -3 gpurun_out/dinow/err_$C.txt
