@@ -580,6 +580,39 @@ def test_driver_degrades_to_one_stream_when_the_queue_request_came_late(dev, mon
         gsbp_amd.ViewPipeline(cfg.n_gaussians, cfg.width, cfg.height, dev)
 
 
+def test_driver_rebuilds_the_field_when_the_ring_kernel_reports_a_stall(dev, monkeypatch):
+    """The producer / consumer form of the encoder-fused kernel bounds its LDS-ring waits and reports a wave that gave up through
+    gwbp_stats.overflow bit 4 (never observed; the bound exists so that a scheduling accident cannot hang the device).  The driver
+    used to raise; it now warns, zeroes the accumulators and builds the field again with the one-wave-per-tile form.  The stall
+    is injected into the first pipeline's counters; the result must equal a run that never used the ring kernel."""
+    from gsbp_amd import backproject as bp
+    cfg, sc = scene_np("T1", n_views=4)
+    d = to_dev(sc, dev)
+    vms = syn.make_cameras(cfg, n_views=4).to(dev)
+    K_in, n_out = 64, 16
+    g = torch.Generator().manual_seed(15)
+    wide = [torch.randn(cfg.height, cfg.width, K_in, generator=g).to(dev) for _ in range(4)]
+    enc = (torch.randn(K_in, n_out, generator=g) / K_in ** 0.5).to(dev)
+    args = (d["means"], d["quats"], d["scales"], d["opac"], vms, d["K"], cfg.width, cfg.height, lambda v: wide[v], K_in)
+    ref = gsbp_amd.create_feature_field(*args, encoder=enc, encoder_split=False, return_partials=True)
+    real_stats, seen = bp.ViewPipeline.stats, []
+
+    def stats(self):
+        st = real_stats(self)
+        seen.append(self.split_encoder)
+        if self.split_encoder:
+            st = dict(st, overflow=st["overflow"] | 16)
+        return st
+
+    monkeypatch.setattr(bp.ViewPipeline, "stats", stats)
+    with pytest.warns(RuntimeWarning, match="encoder_split=False"):
+        got = gsbp_amd.create_feature_field(*args, encoder=enc, encoder_split=True, return_partials=True)
+    assert True in seen and seen[-1] is False  # the ring kernel ran, was reported stalled, the rerun did without it
+    assert got[3]["overflow"] == 0
+    assert rel_row_err(got[1].cpu().numpy(), ref[1].cpu().numpy()) <= 1e-5
+    assert rel_row_err(got[2].cpu().numpy()[:, None], ref[2].cpu().numpy()[:, None]) <= 1e-5
+
+
 def _capture_cases():
     from util import capture_tool
     return capture_tool().CASES
