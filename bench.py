@@ -389,6 +389,13 @@ def main():
         total_pairs, overflow = float(tt[1]), float(tt[2])
         total_views = args.steps
 
+    if overflow:
+        # a view of the timed region was cut short (capacity, kernel mismatch, ring stall ...): no line -- a rate with work skipped
+        # is not a measurement
+        if rank == 0:
+            print(f"bench.py: gwbp_stats.overflow = {int(overflow)} in the timed region (bit 0/1: intersection / pair capacity, "
+                  "2: kernel mismatch, 3: token geometry, 4: ring stall); no result line", file=sys.stderr)
+        raise SystemExit(5)
     fr = [e[0].elapsed_time(e[1]) for e in ev] if not args.serial else [0.0]
     t_front = sum(fr) / len(fr)
     t_scatter = sum(e[2].elapsed_time(e[3]) for e in ev) / args.steps
