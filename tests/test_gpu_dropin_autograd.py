@@ -118,7 +118,7 @@ def test_a_table_rewritten_through_data_is_not_rendered_as_zero(dev):
     with torch.no_grad():
         ref, ref_alpha, _ = rasterization(*args, t.detach().clone(), d["vms"][0][None], d["K"][None], width=W, height=H,
                                           want_meta=False)
-    assert float(out.abs().max()) > 0 and torch.allclose(out, ref, atol=1e-6)
+    assert float(out.detach().abs().max()) > 0 and torch.allclose(out.detach(), ref, atol=1e-6)
     t.data.zero_()
     rz.invalidate_zero_table_cache()
     out, _, _ = rasterization(*args, t, d["vms"][0][None], d["K"][None], width=W, height=H, want_meta=False)
