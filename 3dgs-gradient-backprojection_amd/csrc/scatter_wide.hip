@@ -70,6 +70,9 @@ namespace {
 constexpr int kWide = 256;             // channels per chunk
 constexpr int kHalfPix = kTilePix / 2; // pixels per slab
 constexpr int kThreads = 1024;
+#ifndef GWBP_BIL_UNROLL
+#define GWBP_BIL_UNROLL 1
+#endif
 constexpr int kSlabFloats = kHalfPix * kWide; // 32768 floats = 128 KB
 #ifndef GWBP_VISCAP
 #define GWBP_VISCAP 1024
@@ -360,6 +363,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
     // 'improvements' of the kernel ran into this round).
     static_assert(kUnits == 8, "the slab landing area and the batch buffer are the same eight float4");
     f32x4_t fbuf[kUnits];
+    int bil_y0 = 0;     // BILINEAR, lanes 0..7: first texel row and row weight of the next slab's pixel row `lane`, requested with
+    float bil_ly = 0.f; // the round's records (a round ahead of the staging loop that blends the texels)
     u32 next_claim = 0; // thread 0: the item after this one, claimed when this one was started
     const int wv = (int)uniform(threadIdx.x >> 6);
     auto stage_issue = [&]() __attribute__((always_inline)) {
@@ -390,6 +395,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
                                    __builtin_nontemporal_load(src + 192)};
             }
         } else {
+            if (BILINEAR && !(kAbl & 4) && n_rec != 0 && rbase == 0 && lane <= kTile / 2) {
+                // the staging loop below walks the slab's eight pixel rows; their texel row and weight are table lookups that
+                // used to sit, as a dependent round trip, in front of every iteration's sixteen texel loads.  Lane 8: the same
+                // for the wave's pixel column (wave v stages column v of the tile)
+                const int iy = min(ty * kTile + phase * (kTile / 2) + lane, V.H - 1), ix = min(tx * kTile + wv, V.W - 1);
+                const int32_t *imap = lane < kTile / 2 ? M.ymap + iy : M.xmap + ix;
+                const float *lmap = lane < kTile / 2 ? M.ly + iy : M.lx + ix;
+                bil_y0 = *imap, bil_ly = *lmap;
+            }
             // No slab for the next round: say so.  Without this the buffer's OLD contents count as live from one round's end to
             // the next (a conditional redefinition), i.e. right through the visit loop, and its 32 registers cannot double
             // as the loop's batch buffer.
@@ -427,14 +441,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(76))) void
         // One (pixel, lane) unit per round: 16 dword loads in flight per thread.
         constexpr int kAllB = kHalfPix * 64;
         constexpr int kUnitsB = (kAllB + kThreads - 1) / kThreads;
-#pragma unroll 1
+#pragma unroll GWBP_BIL_UNROLL
         for (int u = 0; u < kUnitsB; ++u) {
             const int idx = min(u * kThreads + (int)threadIdx.x, kAllB - 1);
-            const int pix = phase * kHalfPix + (idx >> 6);
-            const int ix = min(tx * kTile + (pix & 15), V.W - 1), iy = min(ty * kTile + (pix >> 4), V.H - 1);
-            const int y0 = M.ymap[iy], x0 = M.xmap[ix];
+            static_assert(kThreads == 16 * 64 && kHalfPix == 8 * kTile, "iteration u of the staging loop = pixel row u of the slab");
+            // (indices and weights requested by stage_issue a round ago; pix & 15 == wv, pix >> 4 == phase * 8 + u)
+            const int y0 = __builtin_amdgcn_readlane(bil_y0, u), x0 = __builtin_amdgcn_readlane(bil_y0, kTile / 2);
             const int y1 = min(y0 + 1, M.lr_h - 1), x1 = min(x0 + 1, M.lr_w - 1);
-            const float h1w = M.ly[iy], w1 = M.lx[ix], h0w = 1.0f - h1w, w0 = 1.0f - w1;
+            const float h1w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bil_ly), u));
+            const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bil_ly), kTile / 2));
+            const float h0w = 1.0f - h1w, w0 = 1.0f - w1;
             const float *b0 = feats + c0 + lane;
             const float *pa = b0 + y0 * M.fs_y + x0 * M.fs_x, *pb = b0 + y0 * M.fs_y + x1 * M.fs_x;
             const float *pc = b0 + y1 * M.fs_y + x0 * M.fs_x, *pd = b0 + y1 * M.fs_y + x1 * M.fs_x;
