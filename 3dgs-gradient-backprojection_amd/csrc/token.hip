@@ -38,11 +38,18 @@ namespace gwbp {
 constexpr int kTokCh = 256;       // channels per wave pass: one float4 per lane
 constexpr int kTokPerWave = 16;   // Gaussians (consecutive in depth order) per wave
 constexpr int kTokWaves = 4;
+#ifndef GWBP_TOK_FLIGHT
+#define GWBP_TOK_FLIGHT 1
+#endif
+// entries (token rows x NC chunks) a wave has in flight per inner-loop iteration.  1: 104 registers at NC = 4, i.e. four waves per
+// SIMD leave room for a front-stage wave beside them (2: 118 registers; alone the same 0.87 ms, the DINO64 step 1.3 % slower)
+constexpr int kTokFlight = GWBP_TOK_FLIGHT;
 constexpr int kTokGroup = kTokPerWave * kTokWaves; // Gaussians per workgroup
 constexpr int kTokMaxTiles = 256;                  // tile columns / rows of the largest view the token path takes (4096 px): 2 KB of
                                                    // LDS tables, so that four workgroups with their 36 KB token windows share a CU
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+
 
 __global__ __launch_bounds__(256) void k_zero_omega(float4 *__restrict__ omega, const Counters *__restrict__ ctr, int prio)
 {
@@ -208,11 +215,11 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                     u64 hits = nz & __ballot(inside);
                     miss = nz & ~hits;
                     const int woff = (er * 3 + ec) * kCW; // (floats; only read from lanes inside)
-                    while (hits != 0ull) {                // two entries' rows in flight
-                        f4 t[2][NC];
-                        float w[2];
+                    while (hits != 0ull) {                // kTokFlight entries' rows in flight
+                        f4 t[kTokFlight][NC];
+                        float w[kTokFlight];
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < kTokFlight; ++u) {
                             w[u] = 0.f;
                             if (hits != 0ull) { // wave-uniform
                                 const int l = __ffsll((long long)hits) - 1;
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < 2; ++u)
+                        for (int u = 0; u < kTokFlight; ++u)
                             if (w[u] != 0.f) { // (wave-uniform; a skipped slot must not turn 0 x NaN into NaN)
 #pragma unroll
                                 for (int c = 0; c < NC; ++c) {
@@ -241,11 +248,11 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                     return;
                 const long long toff = (long long)tr * A.ts_y + (long long)tc * A.ts_x;
                 const int tlo = (int)(u32)toff, thi = (int)(toff >> 32);
-                while (miss != 0ull) { // two entries' rows (2 x NC loads) in flight
-                    f4 t[2][NC];
-                    float w[2];
+                while (miss != 0ull) { // kTokFlight entries' rows (NC loads each) in flight
+                    f4 t[kTokFlight][NC];
+                    float w[kTokFlight];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < kTokFlight; ++u) {
                         w[u] = 0.f;
                         if (miss != 0ull) { // wave-uniform
                             const int l = __ffsll((long long)miss) - 1;
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(64 * kTokWaves) void k_token_apply(TokenApplyArgs A
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
+                    for (int u = 0; u < kTokFlight; ++u)
                         if (w[u] != 0.f) {
 #pragma unroll
                             for (int c = 0; c < NC; ++c) {
