@@ -80,6 +80,8 @@ def main():
                          "of consecutive views run one after the other on ONE stream, up to depth - 1 views ahead)")
     ap.add_argument("--enc-wgs-per-cu", type=float, default=None, help="C5 tuning: encoder workgroups per CU in the pipeline")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run result check (the `checked` object)")
+    ap.add_argument("--no-grow", action="store_true",
+                    help="test hook: keep the workspaces at --isect-cap even when the untimed capacity check overflows")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for 1 rank (test)")
     ap.add_argument("--exact-binning", action="store_true",
                     help="gsplat's 3-sigma tile binning instead of GWBP_FLAG_TIGHT_BINNING (same F and d either way)")
@@ -194,7 +196,7 @@ def main():
             eng.blend_weights(views[0])
             eng.scatter(views[0], pool[0], F, d, sf, sd, upsample=up)
         st = eng.stats()
-        if not st["overflow"]:
+        if not st["overflow"] or args.no_grow:
             break
         eng.grow(st)
     allow_wide = args.scatter != "narrow"

@@ -156,3 +156,18 @@ def test_bench_line_carries_roofline_cpu_baseline_and_an_oracle_check(dev):
     assert oc["ok"] is True and oc["views"] == 2 and oc["pairs_product"] == oc["pairs_oracle"] > 0
     assert oc["F_max_rel_row_err"] <= 1e-4 and oc["d_max_rel_err"] <= 1e-4
     assert j["checked"]["ok"] is True and j["vs_baseline"] is None and j["dtype"] == "f32" and j["n_gpus"] == 1
+
+
+def test_bench_prints_no_line_for_a_timed_region_that_overflowed(dev):
+    """A view cut short by a capacity overflow is work skipped inside the timed region: bench.py says so on stderr, prints NO result
+    line and exits non-zero (the workspaces normally grow in an untimed check first; --no-grow keeps them at 2000 intersections)."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "6", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-check", "--isect-cap", "2000", "--no-grow"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert "overflow" in r.stderr and "no result line" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+
